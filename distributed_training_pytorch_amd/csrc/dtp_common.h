@@ -1,0 +1,62 @@
+// Common device helpers for the gfx950 (CDNA4, wave64) kernels of this framework.
+// No CUDA-compat layer: this header is written for hipcc --offload-arch=gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                        // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;     // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;     // 8 bytes
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;      // 16x16 accumulator tile slice
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define DTP_WAVE 64
+#define DTP_DEVINL __device__ __forceinline__
+
+DTP_DEVINL float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// Round-to-nearest-even, NaN-preserving (hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950).
+DTP_DEVINL bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+DTP_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// Async global->LDS copy of 16 bytes per lane. LDS destination is wave-uniform base + lane*16.
+DTP_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+// XCD a contiguous run of tile ids for L2 reuse (cdna_hip_programming.md T1). Speed only.
+DTP_DEVINL int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+DTP_DEVINL float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+DTP_DEVINL float wave_reduce_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// Counter-based RNG for dropout: 64-bit mix of (seed, element index) -> uniform [0,1).
+DTP_DEVINL float rng_uniform(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+#define DTP_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -1)

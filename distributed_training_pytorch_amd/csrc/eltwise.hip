@@ -1,0 +1,219 @@
+// Layout / cast / reduction helpers (memory-bound, 16 B per lane) for gfx950:
+//   * colsum:            bias gradient = column sums of dY [rows][C] (deterministic two-pass)
+//   * transpose_bf16:    batched LDS-tiled 2-D transpose (dgrad weight layouts, W^T for linear dgrad)
+//   * nchw_to_nhwc_bf16: f32/bf16/u8 NCHW image batch -> NHWC bf16 with channel padding and optional
+//                        (x/255 - mean)/std normalisation fused (ship uint8 over PCIe)
+//   * cast_f32_bf16, relu_mask, pad_last_dim
+#include "dtp_common.h"
+
+static inline int grid_for(size_t work, int block = 256, int cap = 8192) {
+  size_t g = (work + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ colsum
+// pass 1: block b sums rows [b*rpb, (b+1)*rpb) for every column -> part[b][C]
+__global__ void colsum_pass1_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int rows, int C, int ld,
+                                    int rpb) {
+  const int CV = C >> 3;
+  const int lanes_v = CV < 256 ? CV : 256;
+  const int rr_n = 256 / lanes_v;
+  const int v_l = threadIdx.x % lanes_v, rr = threadIdx.x / lanes_v;
+  const int r0 = blockIdx.x * rpb;
+  int r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  __shared__ float red[256 * 8];
+  for (int v0 = 0; v0 < CV; v0 += lanes_v) {
+    const int v = v0 + v_l;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (v < CV && rr < rr_n) {
+      for (int r = r0 + rr; r < r1; r += rr_n) {
+        const u32x4_t q = *(const u32x4_t*)(x + (size_t)r * ld + v * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] += __uint_as_float(q[e] << 16);
+          acc[2 * e + 1] += __uint_as_float(q[e] & 0xFFFF0000u);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+    __syncthreads();
+    if (rr == 0 && v < CV) {
+      for (int k = 1; k < rr_n; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += red[(k * lanes_v + v_l) * 8 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[(size_t)blockIdx.x * C + v * 8 + e] = acc[e];
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: out[c] = beta*out[c] + sum_b part[b][c]
+__global__ void colsum_pass2_kernel(const float* __restrict__ part, int nb, int C, int Cvalid, void* __restrict__ out,
+                                    int out_fp32, float beta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cvalid) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(size_t)b * C + c];
+  if (out_fp32) {
+    float* o = (float*)out;
+    o[c] = (beta != 0.f ? beta * o[c] : 0.f) + s;
+  } else {
+    bf16_t* o = (bf16_t*)out;
+    o[c] = f32_to_bf16((beta != 0.f ? beta * bf16_to_f32(o[c]) : 0.f) + s);
+  }
+}
+
+// x: [rows][ld] bf16 (C <= ld, C % 8 == 0); workspace: >= nblocks*C floats; only Cvalid columns stored
+extern "C" int dtp_colsum(const void* x, void* out, float* workspace, int ws_floats, int rows, int C, int Cvalid,
+                          int ld, int out_fp32, float beta, hipStream_t s) {
+  if (rows <= 0 || C <= 0 || (C & 7) || (ld & 7) || Cvalid > C) return -10;
+  int nb = ws_floats / C;
+  if (nb > 1024) nb = 1024;
+  if (nb > (rows + 31) / 32) nb = (rows + 31) / 32;
+  if (nb < 1) return -11;
+  const int rpb = (rows + nb - 1) / nb;
+  nb = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_pass1_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, workspace, rows, C, ld, rpb);
+  hipLaunchKernelGGL(colsum_pass2_kernel, dim3((Cvalid + 255) / 256), dim3(256), 0, s, workspace, nb, C, Cvalid, out,
+                     out_fp32, beta);
+  return DTP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------ transpose
+// out[b][c][r] = in[b][r][c], 64x64 tiles through LDS (+1 padding), batch offsets may be negative.
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int Cc,
+                                      long ld_in, long ld_out, long in_bs, long out_bs) {
+  __shared__ bf16_t tile[64][66];
+  const bf16_t* ib = in + (long)blockIdx.z * in_bs;
+  bf16_t* ob = out + (long)blockIdx.z * out_bs;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? ib[(long)r * ld_in + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < R) ob[(long)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+extern "C" int dtp_transpose_bf16(const void* in, void* out, int R, int Cc, long ld_in, long ld_out, int batch,
+                                  long in_bs, long out_bs, hipStream_t s) {
+  if (R <= 0 || Cc <= 0 || batch <= 0) return -10;
+  dim3 grid((Cc + 63) / 64, (R + 63) / 64, batch);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, R, Cc, ld_in,
+                     ld_out, in_bs, out_bs);
+  return DTP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------ image ingest
+// in: [N][Cin][H][W] of T (f32 / bf16 / u8) -> out: [N][H][W][Cpad] bf16, channels >= Cin zeroed.
+// normalize: v = (v * scale - mean[c]) * inv_std[c]
+template <typename T>
+DTP_DEVINL float load_as_f32(const T* p);
+template <> DTP_DEVINL float load_as_f32<float>(const float* p) { return *p; }
+template <> DTP_DEVINL float load_as_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <> DTP_DEVINL float load_as_f32<uint8_t>(const uint8_t* p) { return (float)*p; }
+
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const T* __restrict__ in, bf16_t* __restrict__ out, int N, int Cin, int H, int W,
+                                    int Cpad, float scale, const float* __restrict__ mean,
+                                    const float* __restrict__ inv_std) {
+  const int CV = Cpad >> 3;
+  const size_t hw = (size_t)H * W;
+  const size_t total = (size_t)N * hw * CV;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    // pixel fastest within a channel-vector so the NCHW reads of consecutive lanes are contiguous
+    const size_t pix = i % hw;
+    size_t r = i / hw;
+    const int cv = (int)(r % CV);
+    const int n = (int)(r / CV);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cv * 8 + e;
+      float f = 0.f;
+      if (c < Cin) {
+        f = load_as_f32<T>(in + ((size_t)n * Cin + c) * hw + pix) * scale;
+        if (mean) f = (f - mean[c]) * inv_std[c];
+      }
+      v[e] = f;
+    }
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+    *(u32x4_t*)(out + ((size_t)n * hw + pix) * Cpad + cv * 8) = o;
+  }
+}
+
+extern "C" int dtp_nchw_to_nhwc_bf16(const void* in, int in_kind, void* out, int N, int Cin, int H, int W, int Cpad,
+                                     float scale, const float* mean, const float* inv_std, hipStream_t s) {
+  if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || (Cpad & 7) || Cpad < Cin) return -10;
+  const size_t work = (size_t)N * H * W * (Cpad / 8);
+  const int g = grid_for(work);
+  if (in_kind == 0)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)in, (bf16_t*)out, N, Cin, H,
+                       W, Cpad, scale, mean, inv_std);
+  else if (in_kind == 1)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)in, (bf16_t*)out, N, Cin,
+                       H, W, Cpad, scale, mean, inv_std);
+  else if (in_kind == 2)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<uint8_t>, dim3(g), dim3(256), 0, s, (const uint8_t*)in, (bf16_t*)out, N,
+                       Cin, H, W, Cpad, scale, mean, inv_std);
+  else
+    return -11;
+  return DTP_CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------ misc
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+  const size_t nv = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4_t a = *(const f32x4_t*)(in + i * 8), b = *(const f32x4_t*)(in + i * 8 + 4);
+    u32x4_t o;
+    o[0] = pack_bf16x2(a[0], a[1]); o[1] = pack_bf16x2(a[2], a[3]);
+    o[2] = pack_bf16x2(b[0], b[1]); o[3] = pack_bf16x2(b[2], b[3]);
+    *(u32x4_t*)(out + i * 8) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = nv * 8; i < n; ++i) out[i] = f32_to_bf16(in[i]);
+}
+
+extern "C" int dtp_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  if (((uintptr_t)in & 15) || ((uintptr_t)out & 15)) return -10;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, s, in, (bf16_t*)out, n);
+  return DTP_CHECK_LAUNCH();
+}
+
+// g *= (y > 0) * scale, in place or out of place (n % 8 == 0)
+__global__ void relu_mask_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ y, bf16_t* __restrict__ out,
+                                 size_t n, float scale) {
+  const size_t nv = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4_t gv = *(const u32x4_t*)(g + i * 8), yv = *(const u32x4_t*)(y + i * 8);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ylo = __uint_as_float(yv[e] << 16), yhi = __uint_as_float(yv[e] & 0xFFFF0000u);
+      const float glo = __uint_as_float(gv[e] << 16), ghi = __uint_as_float(gv[e] & 0xFFFF0000u);
+      o[e] = pack_bf16x2(ylo > 0.f ? glo * scale : 0.f, yhi > 0.f ? ghi * scale : 0.f);
+    }
+    *(u32x4_t*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int dtp_relu_mask(const void* g, const void* y, void* out, size_t n, float scale, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n & 7) return -10;
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)y,
+                     (bf16_t*)out, n, scale);
+  return DTP_CHECK_LAUNCH();
+}

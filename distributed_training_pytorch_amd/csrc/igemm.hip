@@ -1,0 +1,362 @@
+// Implicit-GEMM 3x3 convolution (forward and data-gradient) and the "NT" linear GEMM, bf16 in,
+// f32 accumulate on MFMA (v_mfma_f32_16x16x32_bf16), for gfx950.
+//
+//   out[m][n] = epilogue( sum_{tap} sum_{c} A[pix(m) + shift(tap)][c] * B[n][tap*C + c] )
+//
+// * A: NHWC activations viewed as a [M = N*H*W][C] row-major matrix (TAPS9) or a plain [M][lda]
+//   matrix (linear, one "tap").  B: [Ncols][ldb] with the reduction axis contiguous.
+// * The K loop walks (tap, 64-channel chunk).  A tiles are fetched with global_load_lds (16 B per
+//   lane, direct to LDS); image-border taps and M/N tails are redirected, per lane, to a zeroed
+//   16-byte page, so there is no materialised im2col and no padding of the tensors.
+// * LDS image: [rows][64 bf16] (128-B rows), XOR-swizzled at 16-B granularity
+//   (chunk ^= (row>>1)&7), applied on the *global source address* because LDS-DMA writes are
+//   lane-linear, and again on the ds_read_b128 address -> conflict-free fragment reads.
+// * Two LDS stages, one barrier per K-step: stage(k+1) is issued before compute(k).
+// * MFMA orientation: weights are the A operand, pixels the B operand, so each lane ends up with
+//   4 consecutive output channels of one pixel -> packed 8-byte LDS writes, then full-row 16-byte
+//   coalesced NHWC stores.  Fused epilogues: +bias, ReLU, dropout (counter RNG), or the
+//   ReLU-backward mask (grad * (act > 0) * scale) used by data-gradient calls.
+// * blockIdx is remapped XCD-aware (bijective) so tiles that share pixels/halos share an L2.
+//
+// Reference parity: replaces cuDNN conv fwd / bwd-data + ATen relu_/threshold_backward and
+// cuBLAS linear that the reference reaches through
+// model/vgg16.py:9-13,71-79.
+#include "dtp_common.h"
+
+struct IgemmParams {
+  const char* A;
+  const char* B;
+  const float* bias;
+  const char* mask_src;   // bf16 [M][ldo]: output is multiplied by (mask_src > 0) * mask_scale
+  char* out;              // bf16 or f32 [M][ldo]
+  float* partial;         // split-K slabs [z][M][Ncols] f32 (when gridDim.y > 1)
+  const char* zero_page;
+  int M, Ncols, C;
+  int H, W;
+  int lda, ldb, ldo;      // in elements
+  int out_fp32;
+  int relu;
+  float mask_scale;
+  float drop_p;
+  unsigned long long seed;
+  int ksteps_total;
+  int ksteps_per_split;
+  int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WGM, int WGN, bool TAPS9>
+__global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmParams p) {
+  constexpr int T = WGM * WGN * 64;
+  constexpr int RP = T / 8;          // tile rows covered by one staging pass (8 lanes per 128-B row)
+  constexpr int AP = BM / RP;
+  constexpr int BP = BN / RP;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int MI = WM / 16, NI = WN / 16;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(AP >= 1 && BP >= 1, "tile too small for the thread count");
+  static_assert(BM * BN * 2 <= 2 * STAGE, "C image must fit in the staging buffers");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int kbeg = blockIdx.y * p.ksteps_per_split;
+  int kend = kbeg + p.ksteps_per_split;
+  if (kend > p.ksteps_total) kend = p.ksteps_total;
+
+  // ---------------- staging set-up (per-lane source pointers, fixed over the K loop)
+  const int srow = tid >> 3;
+  const int pch = tid & 7;
+  const int lch = pch ^ ((srow >> 1) & 7);   // logical 16-B chunk this lane fetches
+  const char* aptr[AP];
+  unsigned amask[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + srow + i * RP;
+    const bool inb = m < p.M;
+    if (TAPS9) {
+      const int hw = p.H * p.W;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int h = rem / p.W;
+      const int w = rem - h * p.W;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+        if (inb && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) mk |= 1u << t;
+      }
+      amask[i] = mk;
+      aptr[i] = p.A + ((size_t)m * p.C + lch * 8) * 2;
+    } else {
+      amask[i] = inb ? 1u : 0u;
+      aptr[i] = p.A + ((size_t)m * p.lda + lch * 8) * 2;
+    }
+  }
+  const char* bptr[BP];
+  bool bok[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int n = n0 + srow + i * RP;
+    bok[i] = n < p.Ncols;
+    bptr[i] = p.B + ((size_t)n * p.ldb + lch * 8) * 2;
+  }
+  const int cchunks = p.C >> 6;   // 64-channel chunks per tap
+
+  auto stage = [&](int kt, int buf) {
+    int tap = 0, cc = kt;
+    if (TAPS9) { tap = kt / cchunks; cc = kt - tap * cchunks; }
+    long koffA, koffB;
+    if (TAPS9) {
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      koffA = ((long)(dy * p.W + dx) * p.C + cc * 64) * 2;
+      koffB = ((long)tap * p.C + cc * 64) * 2;
+    } else {
+      koffA = (long)cc * 128;
+      koffB = (long)cc * 128;
+    }
+    char* lA = smem + buf * STAGE + wave * (8 * 128);
+    char* lB = lA + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const bool ok = (amask[i] >> tap) & 1u;
+      const char* g = ok ? aptr[i] + koffA : p.zero_page;
+      glds16(g, lA + i * RP * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const char* g = bok[i] ? bptr[i] + koffB : p.zero_page;
+      glds16(g, lB + i * RP * 128);
+    }
+  };
+
+  // ---------------- fragment read addresses (per-lane constants)
+  const int frow = lane & 15;
+  const int fk = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
+  // byte offset inside a tile image for k-substep ks: row*128 + ((ks*4 + fk) ^ fsw)*16
+  const int foff0 = frow * 128 + (((0 * 4 + fk) ^ fsw) << 4);
+  const int foff1 = frow * 128 + (((1 * 4 + fk) ^ fsw) << 4);
+  const int a_base = (wm * WM) * 128;              // pixel rows of this wave
+  const int b_base = BM * 128 + (wn * WN) * 128;   // weight rows of this wave
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? foff1 : foff0;
+      bf16x8_t xf[MI], wf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xf[i] = *(const bf16x8_t*)(base + a_base + i * 2048 + fo);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) wf[j] = *(const bf16x8_t*)(base + b_base + j * 2048 + fo);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---------------- main loop: 2 LDS stages, one barrier per K-step
+  if (kbeg < kend) stage(kbeg, 0);
+  int buf = 0;
+  for (int kt = kbeg; kt < kend; ++kt) {
+    __syncthreads();   // stage kt landed everywhere; everyone is done reading the other buffer
+    if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
+    compute(buf);
+    buf ^= 1;
+  }
+
+  // ---------------- epilogue
+  const int prow = lane & 15;          // pixel within a 16-block
+  const int cq = (lane >> 4) * 4;      // first of 4 consecutive channels within a 16-block
+  if (gridDim.y > 1 || p.out_fp32) {
+    // direct register -> global f32 (split-K slabs, or small f32 outputs such as the logits)
+    float* dst = gridDim.y > 1 ? p.partial + (size_t)blockIdx.y * p.M * p.Ncols : (float*)p.out;
+    const int ld = gridDim.y > 1 ? p.Ncols : p.ldo;
+    const bool fuse = gridDim.y == 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm * WM + i * 16 + prow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 16 + cq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < p.Ncols) {
+            float v = acc[i][j][e];
+            if (fuse) {
+              if (p.bias) v += p.bias[n + e];
+              if (p.relu) v = fmaxf(v, 0.f);
+            }
+            dst[(size_t)m * ld + n + e] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  __syncthreads();   // all waves finished reading the staging buffers
+  {
+    const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int nl = wn * WN + j * 16 + cq;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n0 + nl + e < p.Ncols) bv[e] = p.bias[n0 + nl + e];
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int pl = wm * WM + i * 16 + prow;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[i][j][e] + bv[e];
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.drop_p > 0.f) {
+            const uint64_t idx = (uint64_t)(m0 + pl) * (uint64_t)p.Ncols + (uint64_t)(n0 + nl + e);
+            x = rng_uniform(p.seed, idx) >= p.drop_p ? x * keep_scale : 0.f;
+          }
+          v[e] = x;
+        }
+        u32x2_t pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        const int q = nl >> 3;
+        const int addr = pl * (BN * 2) + ((q ^ (pl & 7)) << 4) + ((nl >> 2) & 1) * 8;
+        *(u32x2_t*)(smem + addr) = pk;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int CPR = BN / 8;                 // 16-B chunks per C row
+    constexpr int TOTAL = BM * CPR;
+    for (int id = tid; id < TOTAL; id += T) {
+      const int pl = id / CPR;
+      const int q = id - pl * CPR;
+      const int m = m0 + pl, n = n0 + q * 8;
+      if (m >= p.M || n >= p.Ncols) continue;
+      u32x4_t v = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
+      const size_t goff = ((size_t)m * p.ldo + n) * 2;
+      if (p.mask_src) {
+        const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t mw = mk[e], vw = v[e];
+          // bf16 > 0  <=>  sign clear and magnitude non-zero
+          const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
+          const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
+          float lo = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+          float hi = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+          v[e] = pack_bf16x2(lo, hi);
+        }
+      }
+      *(u32x4_t*)(p.out + goff) = v;
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// split-K reduce + fused epilogue: out = epi(sum_z partial[z])
+__global__ void igemm_splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, int M, int Ncols,
+                                           const float* __restrict__ bias, const bf16_t* __restrict__ mask_src,
+                                           void* __restrict__ out, int ldo, int out_fp32, int relu,
+                                           float mask_scale, float drop_p, unsigned long long seed) {
+  const size_t total = (size_t)M * Ncols;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / Ncols), n = (int)(i - (size_t)m * Ncols);
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += partial[(size_t)z * total + i];
+    if (bias) v += bias[n];
+    if (relu) v = fmaxf(v, 0.f);
+    if (drop_p > 0.f) v = rng_uniform(seed, i) >= drop_p ? v * keep_scale : 0.f;
+    const size_t o = (size_t)m * ldo + n;
+    if (mask_src) v = bf16_to_f32(mask_src[o]) > 0.f ? v * mask_scale : 0.f;
+    if (out_fp32) ((float*)out)[o] = v;
+    else ((bf16_t*)out)[o] = f32_to_bf16(v);
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool TAPS9>
+static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
+  IgemmParams p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.Ncols + BN - 1) / BN;
+  constexpr int lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return -2;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, nsplit, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, stream, p);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, const void* mask_src, void* out,
+                            float* partial, const void* zero_page, int M, int Ncols, int C, int taps, int H,
+                            int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
+                            float drop_p, unsigned long long seed, int nsplit, int cfg, hipStream_t stream) {
+  if (M <= 0 || Ncols <= 0 || C <= 0 || (C & 63)) return -10;          // K chunks are 64 wide
+  if (taps != 1 && taps != 9) return -11;
+  if (taps == 9 && (H <= 0 || W <= 0 || M % (H * W) != 0)) return -12;
+  if (!out_fp32 && ((Ncols & 7) || (ldo & 7))) return -13;               // 16-byte bf16 row chunks
+  if ((lda & 7) || (ldb & 7)) return -14;
+  IgemmParams p;
+  p.A = (const char*)A; p.B = (const char*)B; p.bias = bias; p.mask_src = (const char*)mask_src;
+  p.out = (char*)out; p.partial = partial; p.zero_page = (const char*)zero_page;
+  p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
+  p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
+  p.ksteps_total = taps * (C >> 6);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > p.ksteps_total) nsplit = p.ksteps_total;
+  p.ksteps_per_split = (p.ksteps_total + nsplit - 1) / nsplit;
+  nsplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
+  if (nsplit > 1 && partial == nullptr) return -15;
+  int rc;
+  const bool t9 = taps == 9;
+  switch (cfg) {
+    case 0: rc = t9 ? launch_cfg<256, 256, 2, 4, true>(p, nsplit, stream) : launch_cfg<256, 256, 2, 4, false>(p, nsplit, stream); break;
+    case 1: rc = t9 ? launch_cfg<256, 128, 4, 2, true>(p, nsplit, stream) : launch_cfg<256, 128, 4, 2, false>(p, nsplit, stream); break;
+    case 2: rc = t9 ? launch_cfg<256, 64, 4, 1, true>(p, nsplit, stream) : launch_cfg<256, 64, 4, 1, false>(p, nsplit, stream); break;
+    case 3: rc = t9 ? launch_cfg<128, 128, 2, 2, true>(p, nsplit, stream) : launch_cfg<128, 128, 2, 2, false>(p, nsplit, stream); break;
+    case 4: rc = t9 ? launch_cfg<128, 64, 2, 1, true>(p, nsplit, stream) : launch_cfg<128, 64, 2, 1, false>(p, nsplit, stream); break;
+    default: return -16;
+  }
+  if (rc != 0) return rc;
+  if (nsplit > 1) {
+    const size_t total = (size_t)M * Ncols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, nsplit, M, Ncols,
+                       bias, (const bf16_t*)mask_src, out, ldo, out_fp32, relu, mask_scale, drop_p, seed);
+    return DTP_CHECK_LAUNCH();
+  }
+  return 0;
+}

@@ -1,0 +1,109 @@
+// Fused flat-buffer optimizers for gfx950: one launch updates every parameter of the model.
+// All parameters live in one f32 master arena; gradients in one arena (f32 or bf16); the kernel
+// also emits the bf16 working copy the MFMA kernels read, so no separate cast pass exists.
+// Reference parity: torch.optim.SGD(lr, momentum, weight_decay) foreach path used at
+// example_trainer.py:62,88 — same update rule, incl. dampening/nesterov;
+// AdamW per BASELINE.json north_star.
+#include "dtp_common.h"
+
+template <bool GRAD_BF16>
+DTP_DEVINL f32x4_t load_grad4(const void* g, size_t i4) {
+  if (GRAD_BF16) {
+    const u32x2_t q = *(const u32x2_t*)((const bf16_t*)g + i4 * 4);
+    return (f32x4_t){__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xFFFF0000u),
+                     __uint_as_float(q[1] << 16), __uint_as_float(q[1] & 0xFFFF0000u)};
+  }
+  return *(const f32x4_t*)((const float*)g + i4 * 4);
+}
+
+// torch.optim.SGD semantics:  g += wd*p ; buf = first ? g : m*buf + (1-damp)*g ; g = nesterov ? g + m*buf : buf
+//                             p -= lr*g
+template <bool GRAD_BF16>
+__global__ void sgd_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ mom,
+                                bf16_t* __restrict__ lp, size_t n4, float lr, float momentum, float dampening,
+                                float wd, float grad_scale, int nesterov, int first_step) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t pv = *(const f32x4_t*)(p + i * 4);
+    f32x4_t gv = load_grad4<GRAD_BF16>(g, i) * grad_scale;
+    gv += pv * wd;
+    if (momentum != 0.f) {
+      f32x4_t b;
+      if (first_step) b = gv;
+      else b = *(const f32x4_t*)(mom + i * 4) * momentum + gv * (1.f - dampening);
+      *(f32x4_t*)(mom + i * 4) = b;
+      gv = nesterov ? gv + b * momentum : b;
+    }
+    pv -= gv * lr;
+    *(f32x4_t*)(p + i * 4) = pv;
+    if (lp) {
+      u32x2_t o;
+      o[0] = pack_bf16x2(pv[0], pv[1]);
+      o[1] = pack_bf16x2(pv[2], pv[3]);
+      *(u32x2_t*)(lp + i * 4) = o;
+    }
+  }
+}
+
+// AdamW (decoupled weight decay): p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+template <bool GRAD_BF16>
+__global__ void adamw_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, bf16_t* __restrict__ lp, size_t n4, float lr, float beta1,
+                                  float beta2, float eps, float wd, float grad_scale, float bc1, float bc2_sqrt) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t pv = *(const f32x4_t*)(p + i * 4);
+    const f32x4_t gv = load_grad4<GRAD_BF16>(g, i) * grad_scale;
+    f32x4_t mv = *(const f32x4_t*)(m + i * 4), vv = *(const f32x4_t*)(v + i * 4);
+    pv *= (1.f - lr * wd);
+    mv = mv * beta1 + gv * (1.f - beta1);
+    vv = vv * beta2 + gv * gv * (1.f - beta2);
+    const float step = lr / bc1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[e] -= step * mv[e] / (sqrtf(vv[e]) / bc2_sqrt + eps);
+    *(f32x4_t*)(p + i * 4) = pv;
+    *(f32x4_t*)(m + i * 4) = mv;
+    *(f32x4_t*)(v + i * 4) = vv;
+    if (lp) {
+      u32x2_t o;
+      o[0] = pack_bf16x2(pv[0], pv[1]);
+      o[1] = pack_bf16x2(pv[2], pv[3]);
+      *(u32x2_t*)(lp + i * 4) = o;
+    }
+  }
+}
+
+static inline int grid_for(size_t work) {
+  size_t g = (work + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// n must be a multiple of 4 (the arena pads); all pointers 16-byte aligned.
+extern "C" int dtp_sgd_flat(float* p, const void* g, int grad_bf16, float* mom, void* lp, size_t n, float lr,
+                            float momentum, float dampening, float wd, float grad_scale, int nesterov,
+                            int first_step, hipStream_t s) {
+  if (n == 0 || (n & 3)) return -10;
+  if (momentum != 0.f && mom == nullptr) return -11;
+  if (grad_bf16)
+    hipLaunchKernelGGL(sgd_flat_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, mom, (bf16_t*)lp, n / 4, lr,
+                       momentum, dampening, wd, grad_scale, nesterov, first_step);
+  else
+    hipLaunchKernelGGL(sgd_flat_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, mom, (bf16_t*)lp, n / 4,
+                       lr, momentum, dampening, wd, grad_scale, nesterov, first_step);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_adamw_flat(float* p, const void* g, int grad_bf16, float* m, float* v, void* lp, size_t n, float lr,
+                              float beta1, float beta2, float eps, float wd, float grad_scale, int step,
+                              hipStream_t s) {
+  if (n == 0 || (n & 3) || step < 1) return -10;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+  if (grad_bf16)
+    hipLaunchKernelGGL(adamw_flat_kernel<true>, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16_t*)lp, n / 4,
+                       lr, beta1, beta2, eps, wd, grad_scale, bc1, bc2_sqrt);
+  else
+    hipLaunchKernelGGL(adamw_flat_kernel<false>, dim3(grid_for(n / 4)), dim3(256), 0, s, p, g, m, v, (bf16_t*)lp, n / 4,
+                       lr, beta1, beta2, eps, wd, grad_scale, bc1, bc2_sqrt);
+  return DTP_CHECK_LAUNCH();
+}

@@ -1,0 +1,197 @@
+// NHWC bf16 pooling kernels for gfx950: 2x2/s2 max-pool forward/backward (vectorised 16 B per
+// lane, scatter-free backward with the ReLU-backward mask fused in) and the
+// AdaptiveAvgPool(OHxOW)+flatten pair that hands the feature map to the classifier in the
+// reference's CHW-flatten order (reference model/vgg16.py:14,34,67-70).
+#include "dtp_common.h"
+
+DTP_DEVINL void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __uint_as_float(v[e] << 16);
+    f[2 * e + 1] = __uint_as_float(v[e] & 0xFFFF0000u);
+  }
+}
+
+// Each thread: one output pixel x 8 channels. Windows never overlap (k=2, s=2); odd trailing
+// row/column is dropped like torch's floor mode.
+__global__ void maxpool2x2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W,
+                                      int C) {
+  const int OH = H >> 1, OW = W >> 1, CV = C >> 3;
+  const size_t total = (size_t)N * OH * OW * CV;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    size_t r = i / CV;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const size_t base = (((size_t)n * H + 2 * oh) * W + 2 * ow) * C + cv * 8;
+    const u32x4_t a = *(const u32x4_t*)(x + base);
+    const u32x4_t b = *(const u32x4_t*)(x + base + C);
+    const u32x4_t c = *(const u32x4_t*)(x + base + (size_t)W * C);
+    const u32x4_t d = *(const u32x4_t*)(x + base + (size_t)W * C + C);
+    float fa[8], fb[8], fc[8], fd[8];
+    unpack8(a, fa); unpack8(b, fb); unpack8(c, fc); unpack8(d, fd);
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = fmaxf(fmaxf(fa[2 * e], fb[2 * e]), fmaxf(fc[2 * e], fd[2 * e]));
+      const float hi = fmaxf(fmaxf(fa[2 * e + 1], fb[2 * e + 1]), fmaxf(fc[2 * e + 1], fd[2 * e + 1]));
+      o[e] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);   // exact: inputs are bf16
+    }
+    *(u32x4_t*)(y + (((size_t)n * OH + oh) * OW + ow) * C + cv * 8) = o;
+  }
+}
+
+// dx = dy routed to the FIRST maximal element of each window (torch's tie rule), optionally
+// multiplied by (x > 0): the ReLU that precedes the pool in every VGG block.
+__global__ void maxpool2x2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                      bf16_t* __restrict__ dx, int N, int H, int W, int C, int relu_mask) {
+  const int OH = H >> 1, OW = W >> 1, CV = C >> 3;
+  const size_t total = (size_t)N * OH * OW * CV;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    size_t r = i / CV;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const size_t base = (((size_t)n * H + 2 * oh) * W + 2 * ow) * C + cv * 8;
+    const size_t o01 = C, o10 = (size_t)W * C, o11 = (size_t)W * C + C;
+    float fa[8], fb[8], fc[8], fd[8], g[8];
+    unpack8(*(const u32x4_t*)(x + base), fa);
+    unpack8(*(const u32x4_t*)(x + base + o01), fb);
+    unpack8(*(const u32x4_t*)(x + base + o10), fc);
+    unpack8(*(const u32x4_t*)(x + base + o11), fd);
+    unpack8(*(const u32x4_t*)(dy + (((size_t)n * OH + oh) * OW + ow) * C + cv * 8), g);
+    float ra[8], rb[8], rc[8], rd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int arg = 0; float m = fa[e];
+      if (fb[e] > m) { m = fb[e]; arg = 1; }
+      if (fc[e] > m) { m = fc[e]; arg = 2; }
+      if (fd[e] > m) { m = fd[e]; arg = 3; }
+      const float gv = (relu_mask && !(m > 0.f)) ? 0.f : g[e];
+      ra[e] = arg == 0 ? gv : 0.f; rb[e] = arg == 1 ? gv : 0.f;
+      rc[e] = arg == 2 ? gv : 0.f; rd[e] = arg == 3 ? gv : 0.f;
+    }
+    u32x4_t oa, ob, oc, od;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      oa[e] = (__float_as_uint(ra[2 * e]) >> 16) | (__float_as_uint(ra[2 * e + 1]) & 0xFFFF0000u);
+      ob[e] = (__float_as_uint(rb[2 * e]) >> 16) | (__float_as_uint(rb[2 * e + 1]) & 0xFFFF0000u);
+      oc[e] = (__float_as_uint(rc[2 * e]) >> 16) | (__float_as_uint(rc[2 * e + 1]) & 0xFFFF0000u);
+      od[e] = (__float_as_uint(rd[2 * e]) >> 16) | (__float_as_uint(rd[2 * e + 1]) & 0xFFFF0000u);
+    }
+    *(u32x4_t*)(dx + base) = oa;
+    *(u32x4_t*)(dx + base + o01) = ob;
+    *(u32x4_t*)(dx + base + o10) = oc;
+    *(u32x4_t*)(dx + base + o11) = od;
+  }
+}
+
+// Odd H or W: the dropped last row/column gets zero gradient.
+__global__ void zero_tail_kernel(bf16_t* __restrict__ dx, int N, int H, int W, int C) {
+  const int OH2 = (H >> 1) * 2, OW2 = (W >> 1) * 2;
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    size_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    if (h >= OH2 || w >= OW2) dx[i] = 0;
+  }
+}
+
+DTP_DEVINL int win_start(int o, int in, int out) { return (o * in) / out; }
+DTP_DEVINL int win_end(int o, int in, int out) { return ((o + 1) * in + out - 1) / out; }
+
+// y[n][c*OH*OW + oh*OW + ow] = mean over the adaptive window of x[n][h][w][c]   (NHWC -> CHW-flat)
+__global__ void avgpool_flatten_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H,
+                                           int W, int C, int OH, int OW) {
+  const size_t total = (size_t)N * OH * OW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);          // c fastest: coalesced NHWC reads
+    size_t r = i / C;
+    const int ow = (int)(r % OW); r /= OW;
+    const int oh = (int)(r % OH);
+    const int n = (int)(r / OH);
+    const int h0 = win_start(oh, H, OH), h1 = win_end(oh, H, OH);
+    const int w0 = win_start(ow, W, OW), w1 = win_end(ow, W, OW);
+    float s = 0.f;
+    for (int h = h0; h < h1; ++h)
+      for (int w = w0; w < w1; ++w) s += bf16_to_f32(x[(((size_t)n * H + h) * W + w) * C + c]);
+    s /= (float)((h1 - h0) * (w1 - w0));
+    y[(size_t)n * C * OH * OW + (size_t)c * OH * OW + oh * OW + ow] = f32_to_bf16(s);
+  }
+}
+
+__global__ void avgpool_flatten_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N, int H,
+                                           int W, int C, int OH, int OW) {
+  const size_t total = (size_t)N * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int w = (int)(r % W); r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float s = 0.f;
+    for (int oh = 0; oh < OH; ++oh) {
+      const int h0 = win_start(oh, H, OH), h1 = win_end(oh, H, OH);
+      if (h < h0 || h >= h1) continue;
+      for (int ow = 0; ow < OW; ++ow) {
+        const int w0 = win_start(ow, W, OW), w1 = win_end(ow, W, OW);
+        if (w < w0 || w >= w1) continue;
+        s += bf16_to_f32(dy[(size_t)n * C * OH * OW + (size_t)c * OH * OW + oh * OW + ow]) /
+             (float)((h1 - h0) * (w1 - w0));
+      }
+    }
+    dx[i] = f32_to_bf16(s);
+  }
+}
+
+static inline int grid_for(size_t work, int block = 256, int cap = 8192) {
+  size_t g = (work + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int dtp_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, int C, hipStream_t s) {
+  if (N <= 0 || H < 2 || W < 2 || (C & 7)) return -10;
+  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(grid_for(work)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, N,
+                     H, W, C);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                                  int relu_mask, hipStream_t s) {
+  if (N <= 0 || H < 2 || W < 2 || (C & 7)) return -10;
+  if ((H & 1) || (W & 1)) {
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, s, (bf16_t*)dx, N, H,
+                       W, C);
+  }
+  const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(work)), dim3(256), 0, s, (const bf16_t*)x,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, relu_mask);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_avgpool_flatten_fwd(const void* x, void* y, int N, int H, int W, int C, int OH, int OW,
+                                       hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return -10;
+  hipLaunchKernelGGL(avgpool_flatten_fwd_kernel, dim3(grid_for((size_t)N * OH * OW * C)), dim3(256), 0, s,
+                     (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_avgpool_flatten_bwd(const void* dy, void* dx, int N, int H, int W, int C, int OH, int OW,
+                                       hipStream_t s) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return -10;
+  hipLaunchKernelGGL(avgpool_flatten_bwd_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, s,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, OH, OW);
+  return DTP_CHECK_LAUNCH();
+}

@@ -1,0 +1,138 @@
+"""VGG16 (configuration D) on the fused HIP ops, checkpoint-compatible with the reference.
+
+Parity target: reference ``model/vgg16.py:5-80`` — five ``ConvBlock``s (2,2,3,3,3 conv3x3+ReLU,
+each block ending in MaxPool 2x2), ``AdaptiveAvgPool2d((7,7))``, flatten, ``linear1`` 25088->4096,
+``linear2`` 4096->4096, ``linear3`` 4096->out_channels, one shared ReLU and Dropout(0.3); Kaiming
+(fan_out) conv init, N(0, 0.01) linear init, zero biases (``:49-57``).
+
+``state_dict`` keys are identical (``backbone.{b}.conv.{i}.weight|bias``, ``linear{1,2,3}.*``;
+SURVEY.md §2.3): convolutions sit at the even indices of ``ConvBlock.conv`` and a parameter-less
+``ReLUMarker`` keeps the odd indices occupied, because on the GPU the ReLU is an epilogue of the
+conv kernel.  Values are emitted as contiguous fp32 NCHW tensors, so a stock ``torch.nn`` VGG16
+(or the reference's ``eval.py``) loads them unchanged.
+
+Differences on purpose: ``in_channels`` is honoured (reference ignores it, quirk #22); GPU compute
+is bf16 with f32 accumulation against fp32 master weights held in a flat ``ParamArena``.
+"""
+import torch
+import torch.nn as nn
+
+from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, FusedLayer, Linear, MaxPool2x2,
+                          ReLUMarker)
+from .param_arena import ParamArena
+
+
+class BatchNormNHWC(nn.BatchNorm2d):
+    """BatchNorm over the channel axis of the internal NHWC bf16 layout (VGG16-BN variant).
+    Stays on PyTorch-ROCm's batch-norm kernels (explicit decision): the tensor is
+    handed over as a channels_last NCHW *view*, no copy."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return super().forward(x)
+        y = super().forward(x.permute(0, 3, 1, 2))
+        return y.permute(0, 2, 3, 1).contiguous()
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_layers=2, first=False, batch_norm=False):
+        super().__init__()
+        layers = []
+        for i in range(num_layers):
+            cin = in_channels if i == 0 else out_channels
+            fused_relu = not batch_norm
+            if first and i == 0:
+                conv = ConvFirst(cin, out_channels, relu=fused_relu, grad_premasked=fused_relu)
+            else:
+                # the input of a block's first conv is a pool output: its mask is applied by the
+                # pool backward, so only convs fed directly by a fused conv+ReLU mask their dgrad
+                conv = Conv3x3(cin, out_channels, relu=fused_relu,
+                               input_is_relu_out=(i > 0 and fused_relu), grad_premasked=fused_relu)
+            layers.append(conv)
+            if batch_norm:
+                layers.append(BatchNormNHWC(out_channels))
+            layers.append(ReLUMarker(active=batch_norm))
+        layers.append(MaxPool2x2(relu_mask=not batch_norm))
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class VGG16(nn.Module):
+    def __init__(self, in_channels=3, out_channels=1, init_weights=True, batch_norm=False,
+                 dropout=0.3, grad_dtype=torch.float32):
+        super().__init__()
+        self.batch_norm = batch_norm
+        self.grad_dtype = grad_dtype
+        self.backbone = nn.Sequential(ConvBlock(in_channels, 64, first=True, batch_norm=batch_norm),
+                                      ConvBlock(64, 128, batch_norm=batch_norm),
+                                      ConvBlock(128, 256, num_layers=3, batch_norm=batch_norm),
+                                      ConvBlock(256, 512, num_layers=3, batch_norm=batch_norm),
+                                      ConvBlock(512, 512, num_layers=3, batch_norm=batch_norm))
+        self.avgpool = AvgPoolFlatten((7, 7))
+        self.linear1 = Linear(512 * 7 * 7, 4096, relu=True, drop_p=dropout, grad_premasked=True)
+        self.linear2 = Linear(4096, 4096, relu=True, drop_p=dropout, input_is_relu_out=True,
+                              input_drop_p=dropout, grad_premasked=True)
+        # kept for attribute parity with the reference (model/vgg16.py:39-40); fused on the GPU
+        self.relu = ReLUMarker()
+        self.dropout = nn.Dropout(dropout)
+        self.linear3 = Linear(4096, out_channels, out_fp32=True, input_is_relu_out=True,
+                              input_drop_p=dropout)
+        if init_weights:
+            self._initialize_weights()
+        self.param_arena = None
+        self._register_state_dict_hook(_contiguous_state_dict_hook)
+        self._attach_arena()
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, (Conv3x3, ConvFirst)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    # ------------------------------------------------------------------ arena management
+    def _attach_arena(self):
+        object.__setattr__(self, "param_arena", ParamArena(self, grad_dtype=self.grad_dtype))
+        on_gpu = self.param_arena.device.type == "cuda"
+        for m in self.modules():
+            if isinstance(m, FusedLayer):
+                object.__setattr__(m, "_arena", self.param_arena)
+                if on_gpu:
+                    for p in m.parameters(recurse=False):
+                        self.param_arena.kernel_written.add(id(p))
+                m._derived, m._derived_epoch = {}, -1
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self._attach_arena()     # parameters were re-created/moved: re-home them in a fresh arena
+        return out
+
+    def set_grad_dtype(self, dtype):
+        self.grad_dtype = dtype
+        self._attach_arena()
+
+    def forward(self, x):
+        if x.is_cuda:
+            self.param_arena.refresh_lp()
+        x = self.backbone(x)
+        x = self.avgpool(x)
+        x = self.linear1(x)      # + ReLU + dropout fused
+        x = self.linear2(x)
+        return self.linear3(x)
+
+
+def _contiguous_state_dict_hook(module, state_dict, prefix, local_metadata):
+    """Emit standalone, contiguous fp32 tensors (not views of the 537 MB arena)."""
+    for k in list(state_dict.keys()):
+        v = state_dict[k]
+        if torch.is_tensor(v) and k.startswith(prefix):
+            state_dict[k] = v.detach().clone(memory_format=torch.contiguous_format)
+    return state_dict
+
+
+def vgg16_bn(in_channels=3, out_channels=1, **kw):
+    return VGG16(in_channels, out_channels, batch_norm=True, **kw)

@@ -1,0 +1,367 @@
+"""Raw (non-autograd) Python entry points of the HIP kernels, with host-side shape checks.
+
+Every function validates operand shapes/dtypes/contiguity *before* the launch (a faulting kernel
+can reset the GPU), picks a tile configuration / split-K factor for 256 CUs in 8 XCDs, and
+launches on the caller's current HIP stream.  Tensors are internal-layout: activations NHWC bf16
+``[N, H, W, C]``, conv weights ``[Cout, 9*Cin]`` (tap-major, channel-minor), linear weights
+``[out, in]``.
+"""
+import torch
+
+from .. import _lib
+from .._lib import ptr, stream, check, workspace
+
+BF16 = torch.bfloat16
+N_CU = 256
+
+# (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
+IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64)}
+WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
+
+_overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
+
+
+def _need(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if t.data_ptr() % 16 != 0:
+        raise ValueError("%s must be 16-byte aligned" % name)
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def pick_igemm(M, N, ksteps):
+    """Largest tile that still yields >= ~2 workgroups per CU; split-K when the grid is tiny."""
+    if "igemm" in _overrides:
+        return _overrides["igemm"](M, N, ksteps)
+    if N > 128:
+        order = [0, 3]
+    elif N > 64:
+        order = [1, 3]
+    else:
+        order = [2, 4]
+    cfg = order[-1]
+    for c in order:
+        bm, bn = IGEMM_TILES[c]
+        if _cdiv(M, bm) * _cdiv(N, bn) >= 2 * N_CU:
+            cfg = c
+            break
+    bm, bn = IGEMM_TILES[cfg]
+    tiles = _cdiv(M, bm) * _cdiv(N, bn)
+    nsplit = 1
+    if tiles < N_CU and ksteps >= 16:
+        nsplit = max(1, min(ksteps // 8, _cdiv(2 * N_CU, tiles)))
+    return cfg, nsplit
+
+
+def pick_wgrad(M, C, taps, ksteps):
+    if "wgrad" in _overrides:
+        return _overrides["wgrad"](M, C, taps, ksteps)
+    if taps == 9:
+        if M >= 256 and C % 256 == 0:
+            cfg = 0
+        elif M >= 128 and C % 128 == 0:
+            cfg = 1
+        elif M >= 128:
+            cfg = 2
+        elif C % 128 == 0:
+            cfg = 3
+        else:
+            cfg = 4
+    else:
+        if M >= 256 and C >= 256:
+            cfg = 0
+        elif M >= 128:
+            cfg = 1 if C >= 128 else 2
+        else:
+            cfg = 3 if C >= 128 else 4
+    bm, bn = WGRAD_TILES[cfg]
+    tiles = _cdiv(M, bm) * (taps * (C // bn) if taps == 9 else _cdiv(C, bn))
+    nsplit = max(1, min(ksteps // 8 if ksteps >= 16 else 1, _cdiv(4 * N_CU, tiles)))
+    return cfg, nsplit
+
+
+def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
+           mask_scale, drop_p, seed):
+    ksteps = taps * (C // 64)
+    cfg, nsplit = pick_igemm(M, Ncols, ksteps)
+    partial = None
+    if nsplit > 1:
+        partial = workspace.get("igemm_partial", nsplit * M * Ncols, torch.float32, A.device)
+    rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial),
+                                 ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
+                                 int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
+                                 nsplit, cfg, stream())
+    check(rc, "igemm_nt")
+    return out
+
+
+def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
+    """y = relu(conv3x3_same(x, w) + bias); x [N,H,W,C] bf16, w [Cout, 9*C] bf16, bias f32 [Cout]."""
+    _need(x, BF16, "x")
+    _need(w, BF16, "w")
+    N, H, W, C = x.shape
+    Cout = w.shape[0]
+    if w.numel() != Cout * 9 * C or C % 64 or Cout % 8:
+        raise ValueError("conv3x3_fprop: bad shapes x=%s w=%s" % (tuple(x.shape), tuple(w.shape)))
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+        if bias.numel() != Cout:
+            raise ValueError("bias size")
+    if out is None:
+        out = torch.empty((N, H, W, Cout), dtype=BF16, device=x.device)
+    else:
+        _need(out, BF16, "out")
+        if out.numel() != N * H * W * Cout:
+            raise ValueError("out size")
+    return _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0)
+
+
+def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
+    """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout]."""
+    _need(dy, BF16, "dy")
+    _need(wd, BF16, "wd")
+    N, H, W, Co = dy.shape
+    Cin = wd.shape[0]
+    if wd.numel() != Cin * 9 * Co or Co % 64 or Cin % 8:
+        raise ValueError("conv3x3_dgrad: bad shapes dy=%s wd=%s" % (tuple(dy.shape), tuple(wd.shape)))
+    if mask_src is not None:
+        _need(mask_src, BF16, "mask_src")
+        if mask_src.numel() != N * H * W * Cin:
+            raise ValueError("mask_src size")
+    if out is None:
+        out = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
+    return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
+                  mask_scale, 0.0, 0)
+
+
+def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None):
+    """y = x @ w.T (+bias)(relu)(dropout); x [M,K] bf16, w [Nout,K] bf16."""
+    _need(x, BF16, "x")
+    _need(w, BF16, "w")
+    M, K = x.shape
+    Nout = w.shape[0]
+    if w.shape[1] != K or K % 64:
+        raise ValueError("linear_fwd: bad shapes x=%s w=%s" % (tuple(x.shape), tuple(w.shape)))
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    if not out_fp32 and Nout % 8:
+        raise ValueError("bf16 output needs out_features % 8 == 0 (use out_fp32)")
+    if out is None:
+        out = torch.empty((M, Nout), dtype=torch.float32 if out_fp32 else BF16, device=x.device)
+    return _igemm(x, w, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed)
+
+
+def linear_dgrad(dy, wt, ld_dy=None, mask_src=None, mask_scale=1.0, out=None):
+    """dx = dy @ W with W given transposed (wt = W.T as [K_in, N_out_padded]); dy [M, ld] bf16."""
+    _need(dy, BF16, "dy")
+    _need(wt, BF16, "wt")
+    M, ld = dy.shape
+    Kin, Nred = wt.shape
+    if Nred != ld or ld % 64 or Kin % 8:
+        raise ValueError("linear_dgrad: bad shapes dy=%s wt=%s" % (tuple(dy.shape), tuple(wt.shape)))
+    if mask_src is not None:
+        _need(mask_src, BF16, "mask_src")
+        if tuple(mask_src.shape) != (M, Kin):
+            raise ValueError("mask_src shape")
+    if out is None:
+        out = torch.empty((M, Kin), dtype=BF16, device=dy.device)
+    return _igemm(dy, wt, None, mask_src, out, M, Kin, ld, 1, 1, 1, ld, ld, Kin, False, False, mask_scale, 0.0, 0)
+
+
+def _wgrad(dy2d, x2d, out, K, M, Ntot, C, taps, H, W, lda, ldb, beta):
+    ksteps = _cdiv(K, 64)
+    cfg, nsplit = pick_wgrad(M, C if taps == 9 else Ntot, taps, ksteps)
+    partial = None
+    if nsplit > 1:
+        partial = workspace.get("wgrad_partial", nsplit * M * Ntot, torch.float32, dy2d.device)
+    out_fp32 = out.dtype == torch.float32
+    rc = _lib.hip().dtp_wgrad_tt(ptr(dy2d), ptr(x2d), ptr(out), ptr(partial), ptr(workspace.zero_page(dy2d.device)),
+                                 K, M, Ntot, C, taps, H, W, lda, ldb, int(out_fp32), float(beta), nsplit, cfg,
+                                 stream())
+    check(rc, "wgrad_tt")
+    return out
+
+
+def conv3x3_wgrad(dy, x, out, beta=0.0):
+    """out[Cout, 9*C] (f32 or bf16, row-major) = beta*out + sum_pixels dy (x) shifted x."""
+    _need(dy, BF16, "dy")
+    _need(x, BF16, "x")
+    N, H, W, Co = dy.shape
+    C = x.shape[3]
+    if tuple(x.shape[:3]) != (N, H, W) or C % 64 or Co % 8:
+        raise ValueError("conv3x3_wgrad: bad shapes dy=%s x=%s" % (tuple(dy.shape), tuple(x.shape)))
+    if out.numel() != Co * 9 * C or not out.is_contiguous() or out.dtype not in (torch.float32, BF16):
+        raise ValueError("conv3x3_wgrad: bad out")
+    return _wgrad(dy, x, out, N * H * W, Co, 9 * C, C, 9, H, W, Co, C, beta)
+
+
+def linear_wgrad(dy, x, out, n_valid=None, beta=0.0):
+    """out[Nout, K] = beta*out + dy[:, :Nout].T @ x ; dy [M, ld>=Nout] bf16, x [M, K] bf16."""
+    _need(dy, BF16, "dy")
+    _need(x, BF16, "x")
+    M, ld = dy.shape
+    K = x.shape[1]
+    Nout = ld if n_valid is None else n_valid
+    if x.shape[0] != M or ld % 8 or K % 8 or Nout > ld:
+        raise ValueError("linear_wgrad: bad shapes dy=%s x=%s" % (tuple(dy.shape), tuple(x.shape)))
+    if out.numel() != Nout * K or not out.is_contiguous() or out.dtype not in (torch.float32, BF16):
+        raise ValueError("linear_wgrad: bad out")
+    return _wgrad(dy, x, out, M, Nout, K, K, 1, 1, 1, ld, K, beta)
+
+
+def colsum(x2d, out, n_valid=None, beta=0.0):
+    """out[:n_valid] = beta*out + column sums of x2d [rows, C] (bias gradient)."""
+    _need(x2d, BF16, "x2d")
+    rows, C = x2d.shape
+    nv = C if n_valid is None else n_valid
+    if C % 8 or out.numel() != nv or out.dtype not in (torch.float32, BF16):
+        raise ValueError("colsum: bad shapes")
+    ws = workspace.get("colsum", 1024 * max(C, 64), torch.float32, x2d.device)
+    rc = _lib.hip().dtp_colsum(ptr(x2d), ptr(out), ptr(ws), ws.numel(), rows, C, nv, C,
+                               int(out.dtype == torch.float32), float(beta), stream())
+    check(rc, "colsum")
+    return out
+
+
+def maxpool2x2_fwd(x):
+    _need(x, BF16, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    check(_lib.hip().dtp_maxpool2x2_fwd(ptr(x), ptr(y), N, H, W, C, stream()), "maxpool_fwd")
+    return y
+
+
+def maxpool2x2_bwd(x, dy, relu_mask=False):
+    _need(x, BF16, "x")
+    _need(dy, BF16, "dy")
+    N, H, W, C = x.shape
+    if tuple(dy.shape) != (N, H // 2, W // 2, C):
+        raise ValueError("maxpool2x2_bwd: dy shape %s" % (tuple(dy.shape),))
+    dx = torch.empty_like(x)
+    check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask), stream()),
+          "maxpool_bwd")
+    return dx
+
+
+def avgpool_flatten_fwd(x, OH=7, OW=7):
+    _need(x, BF16, "x")
+    N, H, W, C = x.shape
+    y = torch.empty((N, C * OH * OW), dtype=BF16, device=x.device)
+    check(_lib.hip().dtp_avgpool_flatten_fwd(ptr(x), ptr(y), N, H, W, C, OH, OW, stream()), "avgpool_fwd")
+    return y
+
+
+def avgpool_flatten_bwd(dy, N, H, W, C, OH=7, OW=7):
+    _need(dy, BF16, "dy")
+    if dy.numel() != N * C * OH * OW:
+        raise ValueError("avgpool_flatten_bwd: dy size")
+    dx = torch.empty((N, H, W, C), dtype=BF16, device=dy.device)
+    check(_lib.hip().dtp_avgpool_flatten_bwd(ptr(dy), ptr(dx), N, H, W, C, OH, OW, stream()), "avgpool_bwd")
+    return dx
+
+
+def transpose_bf16(inp, out, R, Cc, ld_in, ld_out, batch=1, in_bs=0, out_bs=0, in_off=0, out_off=0):
+    """out[b][c][r] = in[b][r][c] on raw strided bf16 storage (element strides/offsets)."""
+    rc = _lib.hip().dtp_transpose_bf16(_lib.c_void_p(inp.data_ptr() + 2 * in_off),
+                                       _lib.c_void_p(out.data_ptr() + 2 * out_off), R, Cc, ld_in, ld_out, batch,
+                                       in_bs, out_bs, stream())
+    check(rc, "transpose")
+    return out
+
+
+def conv_weight_to_dgrad(w, Cout, Cin, out=None):
+    """wd[ci][t][co] = w[co][8-t][ci]  (rotated, channel-transposed filter for the data gradient)."""
+    _need(w, BF16, "w")
+    if w.numel() != Cout * 9 * Cin:
+        raise ValueError("conv_weight_to_dgrad: size")
+    if out is None:
+        out = torch.empty((Cin, 9 * Cout), dtype=BF16, device=w.device)
+    # batch b = tap t of the input; output tap 8-t  -> negative output batch stride
+    return transpose_bf16(w, out, Cout, Cin, 9 * Cin, 9 * Cout, batch=9, in_bs=Cin, out_bs=-Cout,
+                          out_off=8 * Cout)
+
+
+def linear_weight_transpose(w, pad_to=64, out=None):
+    """wt [K_in, ceil(N_out, pad_to)] = w.T, zero padded along N_out (reduction axis of dgrad)."""
+    _need(w, BF16, "w")
+    Nout, K = w.shape
+    ld = _cdiv(Nout, pad_to) * pad_to
+    if out is None:
+        out = (torch.zeros if ld != Nout else torch.empty)((K, ld), dtype=BF16, device=w.device)
+    return transpose_bf16(w, out, Nout, K, K, ld)
+
+
+def nchw_to_nhwc_bf16(x, c_pad, scale=1.0, mean=None, inv_std=None):
+    kinds = {torch.float32: 0, BF16: 1, torch.uint8: 2}
+    if x.dtype not in kinds or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("nchw_to_nhwc_bf16: need contiguous CUDA NCHW f32/bf16/u8")
+    N, Cin, H, W = x.shape
+    out = torch.empty((N, H, W, c_pad), dtype=BF16, device=x.device)
+    rc = _lib.hip().dtp_nchw_to_nhwc_bf16(ptr(x), kinds[x.dtype], ptr(out), N, Cin, H, W, c_pad, float(scale),
+                                          ptr(mean), ptr(inv_std), stream())
+    check(rc, "nchw_to_nhwc")
+    return out
+
+
+def cast_f32_bf16(src, dst):
+    _need(src, torch.float32, "src")
+    _need(dst, BF16, "dst")
+    if src.numel() != dst.numel():
+        raise ValueError("cast size mismatch")
+    check(_lib.hip().dtp_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream()), "cast")
+    return dst
+
+
+def relu_mask(g, y, scale=1.0, out=None):
+    _need(g, BF16, "g")
+    _need(y, BF16, "y")
+    if g.numel() != y.numel() or g.numel() % 8:
+        raise ValueError("relu_mask: size")
+    if out is None:
+        out = torch.empty_like(g)
+    check(_lib.hip().dtp_relu_mask(ptr(g), ptr(y), ptr(out), g.numel(), float(scale), stream()), "relu_mask")
+    return out
+
+
+def softmax_xent(logits, labels, grad_scale=None, want_bf16_grad=True, bf16_ld=None):
+    """Returns (out2 = [mean loss, #hits] f32, dlogits_f32 [N,C], dlogits_bf16 [N,ld] or None)."""
+    _need(logits, torch.float32, "logits")
+    if labels.dtype != torch.int64 or not labels.is_cuda or not labels.is_contiguous():
+        raise ValueError("labels must be contiguous CUDA int64")
+    N, C = logits.shape
+    if labels.numel() != N:
+        raise ValueError("labels size")
+    if grad_scale is None:
+        grad_scale = 1.0 / N
+    ld = bf16_ld if bf16_ld is not None else _cdiv(C, 64) * 64
+    row_ws = torch.empty(2 * N, dtype=torch.float32, device=logits.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+    dl32 = torch.empty((N, C), dtype=torch.float32, device=logits.device)
+    dl16 = torch.empty((N, ld), dtype=BF16, device=logits.device) if want_bf16_grad else None
+    rc = _lib.hip().dtp_softmax_xent(ptr(logits), ptr(labels), ptr(row_ws), ptr(out2), ptr(dl32), ptr(dl16), N, C,
+                                     logits.stride(0), ld, float(grad_scale), 1.0 / N, stream())
+    check(rc, "softmax_xent")
+    return out2, dl32, dl16
+
+
+def sgd_flat(p, g, mom, lp, lr, momentum, dampening, wd, grad_scale, nesterov, first_step):
+    n = p.numel()
+    rc = _lib.hip().dtp_sgd_flat(ptr(p), ptr(g), int(g.dtype == BF16), ptr(mom), ptr(lp), n, float(lr),
+                                 float(momentum), float(dampening), float(wd), float(grad_scale), int(nesterov),
+                                 int(first_step), stream())
+    check(rc, "sgd_flat")
+
+
+def adamw_flat(p, g, m, v, lp, lr, beta1, beta2, eps, wd, grad_scale, step):
+    n = p.numel()
+    rc = _lib.hip().dtp_adamw_flat(ptr(p), ptr(g), int(g.dtype == BF16), ptr(m), ptr(v), ptr(lp), n, float(lr),
+                                   float(beta1), float(beta2), float(eps), float(wd), float(grad_scale), int(step),
+                                   stream())
+    check(rc, "adamw_flat")

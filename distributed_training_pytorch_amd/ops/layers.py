@@ -1,0 +1,374 @@
+"""nn.Modules + autograd Functions over the HIP kernels (GPU) with plain-PyTorch reference
+implementations on CPU (selected by ``device.type == 'cpu'`` only — on a GPU the HIP path is the
+only path and a missing native library is an error).
+
+Internal GPU activation layout is NHWC bf16 ``[N, H, W, C]``; CPU reference layout is NCHW fp32.
+
+Fusion contracts:
+  * ``Conv3x3`` computes conv + bias + ReLU in one kernel;
+  * ReLU-backward is never a kernel of its own: the consumer of an activation applies
+    ``grad * (act > 0)`` in the epilogue of its data-gradient kernel (``input_is_relu_out``) or
+    in the max-pool backward (``relu_mask``); a layer whose incoming gradient is already masked is
+    built with ``grad_premasked=True``;
+  * dropout is an epilogue of the classifier GEMM (counter-based RNG, no mask tensor: the
+    backward mask is ``output != 0``);
+  * weight/bias gradients are written by the kernels straight into the gradient arena
+    (overwrite-on-first-write), the reducer is notified per parameter.
+"""
+import itertools
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels as K
+
+BF16 = torch.bfloat16
+_seed_counter = itertools.count(1)
+
+
+def _arena_of(layer):
+    a = getattr(layer, "_arena", None)
+    if a is None:
+        raise RuntimeError(
+            "%s runs on the GPU only inside a model that owns a ParamArena "
+            "(call models.attach_arena(model) after moving it to the device)" % type(layer).__name__)
+    return a
+
+
+class FusedLayer(nn.Module):
+    """Base: access to the arena's bf16 weight copy and lazily derived dgrad layouts."""
+
+    def __init__(self):
+        super().__init__()
+        self._arena = None
+        self._derived = {}
+        self._derived_epoch = -1
+
+    def bind_arena(self, arena):
+        object.__setattr__(self, "_arena", arena)
+        for p in self.parameters(recurse=False):
+            arena.kernel_written.add(id(p))
+
+    def _cached(self, key, builder):
+        arena = _arena_of(self)
+        if self._derived_epoch != arena.lp_epoch:
+            self._derived = {}
+            self._derived_epoch = arena.lp_epoch
+        v = self._derived.get(key)
+        if v is None:
+            v = builder()
+            self._derived[key] = v
+        return v
+
+
+# =============================================================================== conv 3x3
+class _Conv3x3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        arena = _arena_of(layer)
+        y = K.conv3x3_fprop(x, arena.lp(weight), bias.detach() if bias is not None else None, relu=layer.relu)
+        ctx.layer = layer
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        x, y, weight, bias = ctx.saved_tensors
+        dy = dy.contiguous()
+        if layer.relu and not layer.grad_premasked:
+            dy = K.relu_mask(dy, y)
+        Co = weight.shape[0]
+        K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        if ctx.has_bias:
+            K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Ci = weight.shape[1]
+            wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+        return dx, None, None, None
+
+
+class Conv3x3(FusedLayer):
+    """3x3, stride 1, pad 1 convolution (+bias, +ReLU fused).  ``weight`` keeps torch's logical
+    ``[Cout, Cin, 3, 3]`` shape (checkpoint compatibility with reference model/vgg16.py:9,12)."""
+
+    def __init__(self, in_channels, out_channels, relu=True, input_is_relu_out=False, grad_premasked=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.relu = relu
+        self.input_is_relu_out = input_is_relu_out
+        self.grad_premasked = grad_premasked
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        if not x.is_cuda:
+            y = F.conv2d(x, self.weight, self.bias, padding=1)
+            return F.relu(y) if self.relu else y
+        return _Conv3x3Fn.apply(x, self.weight, self.bias, self)
+
+    def extra_repr(self):
+        return "%d, %d, relu=%s" % (self.in_channels, self.out_channels, self.relu)
+
+
+# =============================================================================== first conv (Cin = 3)
+class _ConvFirstFn(torch.autograd.Function):
+    """Image ingest + first convolution.  The NCHW f32/bf16/u8 batch is converted to NHWC bf16 with
+    the channel axis zero-padded to the 64-wide K chunk of the implicit-GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        arena = _arena_of(layer)
+        xp = K.nchw_to_nhwc_bf16(x.contiguous(), layer.c_pad, layer.in_scale, layer.in_mean, layer.in_inv_std)
+        wp = layer._cached("w_pad", lambda: layer._pad_weight(arena.lp(weight)))
+        y = K.conv3x3_fprop(xp, wp, bias.detach(), relu=layer.relu)
+        ctx.layer = layer
+        ctx.save_for_backward(xp, y, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        xp, y, weight, bias = ctx.saved_tensors
+        dy = dy.contiguous()
+        if layer.relu and not layer.grad_premasked:
+            dy = K.relu_mask(dy, y)
+        Co, Ci = weight.shape[0], weight.shape[1]
+        gpad = K.workspace.get("convfirst_gw", Co * 9 * layer.c_pad, torch.float32, dy.device)
+        gpad = gpad[:Co * 9 * layer.c_pad].view(Co, 9 * layer.c_pad)
+        K.conv3x3_wgrad(dy, xp, gpad, beta=0.0)
+        g = gpad.view(Co, 9, layer.c_pad)[:, :, :Ci]
+        dst = arena.grad(weight).view(Co, 9, Ci)
+        if arena.grad_beta(weight) == 0.0:
+            dst.copy_(g)
+        else:
+            dst.add_(g)
+        K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        return None, None, None, None
+
+
+class ConvFirst(FusedLayer):
+    def __init__(self, in_channels, out_channels, relu=True, grad_premasked=False, c_pad=64):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.relu = relu
+        self.grad_premasked = grad_premasked
+        self.c_pad = c_pad
+        self.in_scale, self.in_mean, self.in_inv_std = 1.0, None, None
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+    def set_input_normalization(self, scale=1.0, mean=None, std=None):
+        """Fuse (x*scale - mean)/std into the ingest kernel (uint8 images over PCIe, K17)."""
+        dev = self.weight.device
+        self.in_scale = float(scale)
+        self.in_mean = None if mean is None else torch.tensor(mean, dtype=torch.float32, device=dev)
+        self.in_inv_std = None if std is None else 1.0 / torch.tensor(std, dtype=torch.float32, device=dev)
+
+    def _pad_weight(self, w_lp):
+        Co, Ci = self.out_channels, self.in_channels
+        wp = torch.zeros((Co, 9, self.c_pad), dtype=BF16, device=w_lp.device)
+        wp[:, :, :Ci] = w_lp.view(Co, 9, Ci)
+        return wp.view(Co, 9 * self.c_pad)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            x = x.float()
+            if self.in_mean is not None or self.in_scale != 1.0:
+                x = x * self.in_scale
+                if self.in_mean is not None:
+                    x = (x - self.in_mean.view(1, -1, 1, 1).to(x.device)) * self.in_inv_std.view(1, -1, 1, 1).to(x.device)
+            y = F.conv2d(x, self.weight, self.bias, padding=1)
+            return F.relu(y) if self.relu else y
+        return _ConvFirstFn.apply(x, self.weight, self.bias, self)
+
+
+# =============================================================================== pooling
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, relu_mask):
+        y = K.maxpool2x2_fwd(x)
+        ctx.relu_mask = relu_mask
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.maxpool2x2_bwd(x, dy.contiguous(), relu_mask=ctx.relu_mask), None
+
+
+class MaxPool2x2(nn.Module):
+    """2x2/s2 max-pool; ``relu_mask=True`` folds the preceding ReLU's backward into the pool
+    backward (then the producer conv is built with ``grad_premasked=True``)."""
+
+    def __init__(self, relu_mask=False):
+        super().__init__()
+        self.relu_mask = relu_mask
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return F.max_pool2d(x, 2, 2)
+        return _MaxPoolFn.apply(x, self.relu_mask)
+
+
+class _AvgPoolFlattenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        ctx.shape = tuple(x.shape)
+        ctx.o = (oh, ow)
+        return K.avgpool_flatten_fwd(x, oh, ow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.shape
+        return K.avgpool_flatten_bwd(dy.contiguous(), N, H, W, C, *ctx.o), None, None
+
+
+class AvgPoolFlatten(nn.Module):
+    """AdaptiveAvgPool2d((7,7)) + flatten in the reference's C,H,W order (model/vgg16.py:34,67-70):
+    on GPU one kernel turns NHWC features into the [N, C*7*7] classifier input."""
+
+    def __init__(self, output_size=(7, 7)):
+        super().__init__()
+        self.output_size = tuple(output_size)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return torch.flatten(F.adaptive_avg_pool2d(x, self.output_size), 1)
+        return _AvgPoolFlattenFn.apply(x, *self.output_size)
+
+
+# =============================================================================== linear
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer, drop_p, seed):
+        arena = _arena_of(layer)
+        y = K.linear_fwd(x, arena.lp(weight), bias.detach(), relu=layer.relu, drop_p=drop_p, seed=seed,
+                         out_fp32=layer.out_fp32)
+        ctx.layer = layer
+        ctx.in_scale = layer._input_mask_scale()
+        ctx.save_for_backward(x, y, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        x, y, weight, bias = ctx.saved_tensors
+        Nout, Kin = weight.shape
+        ld = (Nout + 63) // 64 * 64
+        if dy.dtype != BF16 or dy.shape[1] != ld or not dy.is_contiguous():
+            d16 = torch.zeros((dy.shape[0], ld), dtype=BF16, device=dy.device) if ld != Nout else \
+                torch.empty((dy.shape[0], ld), dtype=BF16, device=dy.device)
+            d16[:, :Nout] = dy
+            dy = d16
+        if (layer.relu or layer.drop_p > 0) and not layer.grad_premasked:
+            scale = 1.0 / (1.0 - layer.drop_p) if (layer.drop_p > 0 and layer.training) else 1.0
+            dy = K.relu_mask(dy, y, scale)
+        K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
+        K.colsum(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
+            dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
+        return dx, None, None, None, None, None
+
+
+class Linear(FusedLayer):
+    """Linear (+bias) with optional fused ReLU and dropout epilogue (order: linear, relu, dropout —
+    reference model/vgg16.py:71-76).  ``out_fp32`` for the logits layer."""
+
+    def __init__(self, in_features, out_features, relu=False, drop_p=0.0, out_fp32=False,
+                 input_is_relu_out=False, input_drop_p=0.0, grad_premasked=False):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.relu, self.drop_p, self.out_fp32 = relu, float(drop_p), out_fp32
+        self.input_is_relu_out = input_is_relu_out
+        self.input_drop_p = float(input_drop_p)
+        self.grad_premasked = grad_premasked
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features))
+        nn.init.normal_(self.weight, 0, 0.01)
+
+    def _input_mask_scale(self):
+        if self.input_is_relu_out and self.input_drop_p > 0 and self.training:
+            return 1.0 / (1.0 - self.input_drop_p)
+        return 1.0
+
+    def forward(self, x):
+        if not x.is_cuda:
+            y = F.linear(x, self.weight, self.bias)
+            if self.relu:
+                y = F.relu(y)
+            if self.drop_p > 0:
+                y = F.dropout(y, self.drop_p, self.training)
+            return y
+        p = self.drop_p if self.training else 0.0
+        seed = (torch.initial_seed() * 1000003 + next(_seed_counter)) & (2 ** 63 - 1) if p > 0 else 0
+        return _LinearFn.apply(x, self.weight, self.bias, self, p, seed)
+
+
+class ReLUMarker(nn.Module):
+    """Parameter-less placeholder that keeps the reference's nn.Sequential indices (a ReLU sits at
+    every odd index of ConvBlock.conv, reference model/vgg16.py:10,13) — the ReLU itself is fused
+    into the preceding kernel.  ``active=True`` makes it a real ReLU (unfused producer)."""
+
+    def __init__(self, active=False):
+        super().__init__()
+        self.active = active
+
+    def forward(self, x):
+        return F.relu(x) if self.active else x
+
+
+# =============================================================================== loss
+class _SoftmaxXentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, holder):
+        out2, dl32, _ = K.softmax_xent(logits.contiguous(), labels.contiguous(), want_bf16_grad=False)
+        ctx.save_for_backward(dl32)
+        holder.last_stats = out2
+        return out2[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl32,) = ctx.saved_tensors
+        return dl32 * g, None, None
+
+
+class SoftmaxCrossEntropy(nn.Module):
+    """Mean softmax cross-entropy; on GPU one fused kernel yields loss, d(logits) and the number of
+    top-1 hits (``last_stats`` = device tensor [loss, hits], no host sync)."""
+
+    def __init__(self):
+        super().__init__()
+        self.last_stats = None
+
+    def forward(self, logits, labels):
+        if not logits.is_cuda:
+            return F.cross_entropy(logits.float(), labels, reduction="mean")
+        return _SoftmaxXentFn.apply(logits.float(), labels, self)
+
+
+def top1_hits(logits, labels):
+    """Number of correct top-1 predictions as a device scalar (argmax on logits: softmax is
+    monotone)."""
+    if not logits.is_cuda:
+        return (logits.argmax(dim=-1) == labels).sum().float()
+    out2, _, _ = K.softmax_xent(logits.float().contiguous(), labels.contiguous(), want_bf16_grad=False)
+    return out2[1]

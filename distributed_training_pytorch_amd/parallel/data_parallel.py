@@ -1,0 +1,80 @@
+"""``DataParallel`` — the module wrapper the Trainer uses instead of stock DDP.
+
+Parity target: reference ``trainer/trainer.py:52`` (``DDP(model, device_ids=[local_rank], ...)``),
+``:88`` (``self.model.module.state_dict()``) and the hook code that calls ``self.model(img)``
+(``example_trainer.py:82,97``): the wrapper exposes ``.module``, is callable, follows
+``train()/eval()`` and offers ``no_sync()``.
+
+What happens at construction: rank 0's parameters and buffers are broadcast
+as a few flat messages; then a :class:`BucketedReducer` takes over gradient synchronisation.
+Buffers (BatchNorm running stats of VGG16-BN) are re-broadcast from rank 0 at the start of a
+*training* forward only — never in eval — which removes the rank-0-only-validation deadlock of
+SURVEY.md §2.6 quirk #9.
+"""
+import torch
+import torch.nn as nn
+
+from . import comm
+from .reducer import BucketedReducer, TorchPGTransport
+
+
+class DataParallel(nn.Module):
+    def __init__(self, module, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
+                 reduce_dtype=None, broadcast_buffers=True, transport=None, sync_init=True):
+        super().__init__()
+        self.module = module
+        self.broadcast_buffers = broadcast_buffers
+        arena = getattr(module, "param_arena", None)
+        params = [p for p in module.parameters() if p.requires_grad]
+        if transport is None:
+            transport = self._pick_transport(params[0].device if params else torch.device("cpu"))
+        kw = dict(bucket_cap_mb=bucket_cap_mb, first_bucket_mb=first_bucket_mb,
+                  split_large_mb=split_large_mb, reduce_dtype=reduce_dtype, transport=transport)
+        if arena is not None and arena.is_flat:
+            self.reducer = BucketedReducer(arena.params, flat_grad=arena.flat_grad,
+                                           flat_offsets=arena.offsets, **kw)
+            arena.reducer = self.reducer
+            self.reducer.pre_ready = arena.sync_autograd_grad
+        else:
+            self.reducer = BucketedReducer(params, **kw)
+        if sync_init and self.reducer.world > 1:
+            self.sync_module_states()
+
+    @staticmethod
+    def _pick_transport(device):
+        if device.type == "cuda" and comm.is_dist() and comm.world_size() > 1:
+            try:
+                from .rccl_native import NativeRcclTransport
+                return NativeRcclTransport()
+            except Exception:
+                pass
+        return TorchPGTransport()
+
+    def sync_module_states(self):
+        arena = getattr(self.module, "param_arena", None)
+        if arena is not None and arena.is_flat:
+            self.reducer.broadcast_parameters([arena.flat_master])
+            arena.mark_master_updated()
+        else:
+            self.reducer.broadcast_parameters([p.data for p in self.module.parameters()])
+        bufs = [b for b in self.module.buffers() if b.numel() > 0 and b.is_floating_point()]
+        if bufs:
+            self.reducer.broadcast_parameters(bufs)
+
+    def forward(self, *args, **kwargs):
+        if (self.broadcast_buffers and self.training and self.reducer.world > 1
+                and self.reducer.require_sync):
+            bufs = [b for b in self.module.buffers() if b.numel() > 0 and b.is_floating_point()
+                    and getattr(b, "_dtp_sync", True)]
+            if bufs:
+                self.reducer.broadcast_parameters(bufs)
+        return self.module(*args, **kwargs)
+
+    def no_sync(self):
+        return self.reducer.no_sync()
+
+    def state_dict(self, *args, **kwargs):
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)

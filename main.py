@@ -1,0 +1,75 @@
+"""Training entry point (reference main.py:4-26): Logger -> ddp_setup -> ExampleTrainer ->
+train() -> destroy_process().  Launch under torchrun via run.sh, or plainly as
+``python main.py --synthetic`` for a single process.
+
+The reference hard-codes every setting as a Python literal; the same literals are the defaults
+here and a thin CLI overlay makes the benchmark configs selectable.
+"""
+import argparse
+
+import torch
+
+from example_trainer import ExampleTrainer
+from utils.logger import Logger
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("--backend", default=None, help="nccl (RCCL) or gloo; default: nccl if a GPU is visible")
+    ap.add_argument("--train-path", default="./data/train")
+    ap.add_argument("--val-path", default="./data/val")
+    ap.add_argument("--synthetic", action="store_true", help="use the deterministic synthetic dataset")
+    ap.add_argument("--synthetic-size", type=int, default=1024)
+    ap.add_argument("--labels", default="cat,dog,snake")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--epochs", type=int, default=300)
+    ap.add_argument("--batch-size", type=int, default=16, help="GLOBAL batch (split over ranks)")
+    ap.add_argument("--lr", type=float, default=0.1)
+    ap.add_argument("--save-period", type=int, default=5)
+    ap.add_argument("--save-folder", default="./runs")
+    ap.add_argument("--snapshot", default=None, help="resume from this snapshot (e.g. runs/weights/last.pth)")
+    ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--batch-norm", action="store_true", help="VGG16-BN variant")
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--grad-accum", type=int, default=1)
+    ap.add_argument("--num-workers", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=None, help="cap on steps per epoch (smoke runs)")
+    ap.add_argument("--no-progress", action="store_true")
+    return ap.parse_args(argv)
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    logger = Logger("VGG16", file="%s/logfile.log" % args.save_folder)
+
+    backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    ExampleTrainer.ddp_setup(backend=backend)
+
+    train_path = "synthetic:%d" % args.synthetic_size if args.synthetic else args.train_path
+    val_path = "synthetic:%d" % max(args.synthetic_size // 4, 1) if args.synthetic else args.val_path
+    trainer = ExampleTrainer(train_path=train_path,
+                             val_path=val_path,
+                             labels=args.labels.split(","),
+                             height=args.image_size,
+                             width=args.image_size,
+                             max_epoch=args.epochs,
+                             batch_size=args.batch_size,
+                             pin_memory=True,
+                             have_validate=not args.no_validate,
+                             save_best_for=("accuracy", "geq"),
+                             save_period=args.save_period,
+                             save_folder=args.save_folder,
+                             snapshot_path=args.snapshot,
+                             logger=logger,
+                             lr=args.lr,
+                             batch_norm=args.batch_norm,
+                             grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32,
+                             grad_accum_steps=args.grad_accum,
+                             num_workers=args.num_workers,
+                             max_steps_per_epoch=args.steps,
+                             progress=not args.no_progress,
+                             metrics_file="%s/metrics.jsonl" % args.save_folder)
+
+    trainer.train()
+
+    ExampleTrainer.destroy_process()

@@ -1,0 +1,342 @@
+"""Numerics of every hand-written HIP kernel against a plain PyTorch fp32 reference of the same op
+(SURVEY.md §4.2 'Kernel numerics' tier).  Inputs are bf16-rounded random data; references are
+computed in fp32 from the same bf16 values, tolerances are those of bf16 storage + f32 accumulate.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16 = torch.bfloat16
+
+
+def _k():
+    from distributed_training_pytorch_amd.ops import kernels
+    return kernels
+
+
+def _rand(*shape, scale=1.0, dev="cuda"):
+    return (torch.randn(*shape, device=dev) * scale).to(BF16)
+
+
+def _close(a, b, rtol, atol, name):
+    a = a.float()
+    b = b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).float().mean().item()
+    assert bad < 1e-4, "%s: %.5f%% elements out of tolerance, max err %.4g (ref max %.4g)" % (
+        name, bad * 100, err.max().item(), b.abs().max().item())
+
+
+def _ref_conv(x_nhwc, w_flat, bias, relu):
+    N, H, W, C = x_nhwc.shape
+    Co = w_flat.shape[0]
+    w = w_flat.float().view(Co, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+    y = F.conv2d(x_nhwc.float().permute(0, 3, 1, 2), w, bias, padding=1)
+    if relu:
+        y = y.relu()
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+CONV_SHAPES = [  # (N, H, W, Cin, Cout)
+    (2, 16, 16, 64, 64),
+    (3, 14, 14, 128, 256),
+    (2, 28, 28, 64, 128),
+    (1, 56, 56, 256, 64),
+    (5, 7, 9, 64, 512),      # odd sizes: M tail + W != H
+    (2, 14, 14, 512, 512),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_fprop(shape):
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(0)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    y = k.conv3x3_fprop(x, w, b, relu=True)
+    ref = _ref_conv(x, w, b, True)
+    _close(y, ref, 2e-2, 2e-2, "fprop%s" % (shape,))
+    y2 = k.conv3x3_fprop(x, w, None, relu=False)
+    _close(y2, _ref_conv(x, w, None, False), 2e-2, 2e-2, "fprop-nobias%s" % (shape,))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_conv3x3_fprop_all_tile_configs(cfg):
+    k = _k()
+    torch.manual_seed(1)
+    N, H, W, C, Co = 2, 20, 12, 128, 256
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    for nsplit in (1, 3):
+        k._overrides["igemm"] = lambda M, Nc, ks: (cfg, nsplit)
+        try:
+            y = k.conv3x3_fprop(x, w, b, relu=True)
+        finally:
+            k._overrides.pop("igemm")
+        _close(y, _ref_conv(x, w, b, True), 2e-2, 2e-2, "cfg%d split%d" % (cfg, nsplit))
+
+
+def test_conv3x3_asymmetric_layout():
+    """A = shifted delta, asymmetric B: catches row/col swaps and tap mirroring."""
+    k = _k()
+    N, H, W, C, Co = 1, 8, 8, 64, 64
+    x = torch.zeros(N, H, W, C, device="cuda")
+    x[0, 3, 4, 5] = 1.0
+    w = torch.arange(Co * 9 * C, device="cuda", dtype=torch.float32).view(Co, 9 * C) % 251 / 251.0
+    xb, wb = x.to(BF16), w.to(BF16)
+    y = k.conv3x3_fprop(xb, wb, None, relu=False)
+    _close(y, _ref_conv(xb, wb, None, False), 1e-2, 1e-3, "delta")
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_dgrad(shape):
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(2)
+    dy = _rand(N, H, W, Co)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * Co)) ** 0.5)
+    xmask = _rand(N, H, W, C)
+    wd = k.conv_weight_to_dgrad(w, Co, C)
+    # reference for the weight transform
+    ref_wd = w.view(Co, 9, C).flip(1).permute(2, 1, 0).reshape(C, 9 * Co)
+    assert torch.equal(wd, ref_wd)
+    dx = k.conv3x3_dgrad(dy, wd, mask_src=xmask, mask_scale=1.0)
+    w4 = w.float().view(Co, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+    ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1)
+    ref = ref * (xmask.float() > 0)
+    _close(dx, ref, 2e-2, 2e-2, "dgrad%s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+@pytest.mark.parametrize("out_dtype", [torch.float32, BF16])
+def test_conv3x3_wgrad(shape, out_dtype):
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(3)
+    x = _rand(N, H, W, C)
+    dy = _rand(N, H, W, Co, scale=0.1)
+    out = torch.full((Co, 9 * C), 7.0, device="cuda", dtype=out_dtype)
+    k.conv3x3_wgrad(dy, x, out, beta=0.0)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    wref = torch.zeros(Co, C, 3, 3, device="cuda", requires_grad=True)
+    yr = F.conv2d(xr, wref, padding=1)
+    (gw,) = torch.autograd.grad(yr, wref, dy.float().permute(0, 3, 1, 2))
+    ref = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    scale = ref.abs().max().item()
+    _close(out, ref, 2e-2, 2e-2 * scale, "wgrad%s" % (shape,))
+    # accumulate (beta = 1)
+    k.conv3x3_wgrad(dy, x, out, beta=1.0)
+    _close(out, 2 * ref, 3e-2, 3e-2 * scale, "wgrad-acc%s" % (shape,))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+def test_conv3x3_wgrad_all_tile_configs(cfg):
+    k = _k()
+    torch.manual_seed(4)
+    N, H, W, C, Co = 3, 10, 14, 256, 256
+    x = _rand(N, H, W, C)
+    dy = _rand(N, H, W, Co, scale=0.1)
+    xr = x.float().permute(0, 3, 1, 2)
+    wref = torch.zeros(Co, C, 3, 3, device="cuda", requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv2d(xr, wref, padding=1), wref, dy.float().permute(0, 3, 1, 2))
+    ref = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    for nsplit in (1, 4):
+        k._overrides["wgrad"] = lambda M, Cc, taps, ks: (cfg, nsplit)
+        try:
+            out = torch.empty((Co, 9 * C), device="cuda")
+            k.conv3x3_wgrad(dy, x, out)
+        finally:
+            k._overrides.pop("wgrad")
+        _close(out, ref, 2e-2, 2e-2 * ref.abs().max().item(), "wgrad cfg%d split%d" % (cfg, nsplit))
+
+
+LIN_SHAPES = [(64, 25088, 4096), (37, 4096, 4096), (16, 512, 1024), (130, 4096, 3)]
+
+
+@pytest.mark.parametrize("shape", LIN_SHAPES)
+def test_linear_fwd_dgrad_wgrad(shape):
+    k = _k()
+    M, K, Nout = shape
+    torch.manual_seed(5)
+    x = _rand(M, K)
+    w = _rand(Nout, K, scale=K ** -0.5)
+    b = torch.randn(Nout, device="cuda")
+    fp32_out = Nout % 8 != 0
+    y = k.linear_fwd(x, w, b, relu=not fp32_out, out_fp32=fp32_out)
+    ref = F.linear(x.float(), w.float(), b)
+    if not fp32_out:
+        ref = ref.relu()
+    _close(y, ref, 2e-2, 2e-2, "linear_fwd%s" % (shape,))
+    # dgrad: dx = dy @ W, via the transposed+padded weight copy
+    ld = (Nout + 63) // 64 * 64
+    dy = torch.zeros(M, ld, device="cuda", dtype=BF16)
+    dy[:, :Nout] = _rand(M, Nout, scale=0.1)
+    wt = k.linear_weight_transpose(w)
+    assert wt.shape == (K, ld) and torch.equal(wt[:, :Nout], w.t())
+    mask = _rand(M, K)
+    dx = k.linear_dgrad(dy, wt, mask_src=mask, mask_scale=1.0 / 0.7)
+    refdx = (dy[:, :Nout].float() @ w.float()) * (mask.float() > 0) / 0.7
+    _close(dx, refdx, 2e-2, 2e-2 * max(refdx.abs().max().item(), 1e-3), "linear_dgrad%s" % (shape,))
+    # wgrad
+    gw = torch.empty(Nout, K, device="cuda")
+    k.linear_wgrad(dy, x, gw, n_valid=Nout)
+    refgw = dy[:, :Nout].float().t() @ x.float()
+    _close(gw, refgw, 2e-2, 2e-2 * refgw.abs().max().item(), "linear_wgrad%s" % (shape,))
+    # bias grad
+    gb = torch.empty(Nout, device="cuda")
+    k.colsum(dy, gb, n_valid=Nout)
+    _close(gb, dy[:, :Nout].float().sum(0), 1e-3, 1e-3, "colsum%s" % (shape,))
+
+
+def test_linear_dropout_statistics_and_determinism():
+    k = _k()
+    torch.manual_seed(6)
+    M, K, Nout = 256, 512, 4096
+    x = _rand(M, K)
+    w = _rand(Nout, K, scale=K ** -0.5)
+    b = torch.ones(Nout, device="cuda") * 3.0      # keep activations positive
+    y0 = k.linear_fwd(x, w, b, relu=True, drop_p=0.0)
+    y1 = k.linear_fwd(x, w, b, relu=True, drop_p=0.3, seed=123)
+    y2 = k.linear_fwd(x, w, b, relu=True, drop_p=0.3, seed=123)
+    y3 = k.linear_fwd(x, w, b, relu=True, drop_p=0.3, seed=124)
+    assert torch.equal(y1, y2)
+    assert not torch.equal(y1, y3)
+    pos = y0.float() > 0
+    dropped = ((y1.float() == 0) & pos).float().sum() / pos.float().sum()
+    assert abs(dropped.item() - 0.3) < 0.01
+    kept = (y1.float() != 0) & pos
+    _close(y1[kept], y0[kept].float() / 0.7, 2e-2, 2e-2, "dropout scale")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (3, 14, 14, 512), (2, 7, 9, 128), (1, 224, 224, 64)])
+def test_maxpool(shape):
+    k = _k()
+    torch.manual_seed(7)
+    N, H, W, C = shape
+    x = _rand(N, H, W, C)
+    # coarse quantisation forces many exact ties (incl. zero ties): tests the first-max rule
+    x = ((x.float() * 2).round() / 2).to(BF16)
+    y = k.maxpool2x2_fwd(x)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    assert torch.equal(y.float(), yr.permute(0, 2, 3, 1))
+    dy = _rand(*y.shape)
+    (gx,) = torch.autograd.grad(yr, xr, dy.float().permute(0, 3, 1, 2))
+    dx = k.maxpool2x2_bwd(x, dy, relu_mask=False)
+    assert torch.equal(dx.float(), gx.permute(0, 2, 3, 1))
+    dxm = k.maxpool2x2_bwd(x, dy, relu_mask=True)
+    assert torch.equal(dxm.float(), (gx * (xr > 0)).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("hw", [(7, 7), (1, 1), (14, 14), (5, 3)])
+def test_avgpool_flatten(hw):
+    k = _k()
+    torch.manual_seed(8)
+    N, C = 3, 64
+    H, W = hw
+    x = _rand(N, H, W, C)
+    y = k.avgpool_flatten_fwd(x)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = torch.flatten(F.adaptive_avg_pool2d(xr, (7, 7)), 1)
+    _close(y, yr, 1e-2, 1e-2, "avgpool fwd")
+    dy = _rand(N, C * 49)
+    (gx,) = torch.autograd.grad(yr, xr, dy.float())
+    dx = k.avgpool_flatten_bwd(dy, N, H, W, C)
+    _close(dx, gx.permute(0, 2, 3, 1), 1e-2, 1e-2, "avgpool bwd")
+
+
+@pytest.mark.parametrize("nc", [(64, 3), (33, 10), (128, 1000)])
+def test_softmax_xent(nc):
+    k = _k()
+    torch.manual_seed(9)
+    N, C = nc
+    logits = torch.randn(N, C, device="cuda") * 3
+    labels = torch.randint(0, C, (N,), device="cuda")
+    out2, dl32, dl16 = k.softmax_xent(logits, labels)
+    lr = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lr, labels)
+    loss.backward()
+    assert abs(out2[0].item() - loss.item()) < 1e-4 * max(1.0, abs(loss.item()))
+    hits = (logits.argmax(1) == labels).sum().item()
+    assert out2[1].item() == hits
+    _close(dl32, lr.grad, 1e-4, 1e-6, "dlogits")
+    _close(dl16[:, :C], lr.grad, 1e-2, 1e-5, "dlogits bf16")
+    assert torch.all(dl16[:, C:] == 0)
+
+
+def test_sgd_and_adamw_flat_match_torch():
+    k = _k()
+    torch.manual_seed(10)
+    n = 1 << 16
+    for gdt in (torch.float32, BF16):
+        p0 = torch.randn(n, device="cuda")
+        ref_p = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.SGD([ref_p], lr=0.1, momentum=0.9, weight_decay=1e-4)
+        p = p0.clone()
+        mom = torch.zeros(n, device="cuda")
+        lp = torch.empty(n, device="cuda", dtype=BF16)
+        for step in range(3):
+            g = torch.randn(n, device="cuda").to(gdt)
+            ref_p.grad = g.float().clone()
+            opt.step()
+            k.sgd_flat(p, g, mom, lp, 0.1, 0.9, 0.0, 1e-4, 1.0, False, step == 0)
+        _close(p, ref_p.data, 1e-5, 1e-6, "sgd %s" % gdt)
+        assert torch.equal(lp, p.to(BF16))
+        ref_p = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.AdamW([ref_p], lr=1e-3, weight_decay=0.01)
+        p = p0.clone()
+        m = torch.zeros(n, device="cuda")
+        v = torch.zeros(n, device="cuda")
+        for step in range(3):
+            g = torch.randn(n, device="cuda").to(gdt)
+            ref_p.grad = g.float().clone()
+            opt.step()
+            k.adamw_flat(p, g, m, v, lp, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, step + 1)
+        _close(p, ref_p.data, 1e-4, 1e-6, "adamw %s" % gdt)
+
+
+def test_nchw_to_nhwc_and_cast_and_relu_mask():
+    k = _k()
+    torch.manual_seed(11)
+    x = torch.randn(2, 3, 9, 11, device="cuda")
+    y = k.nchw_to_nhwc_bf16(x, 64)
+    assert y.shape == (2, 9, 11, 64)
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1).to(BF16))
+    assert torch.all(y[..., 3:] == 0)
+    u8 = torch.randint(0, 256, (2, 3, 9, 11), device="cuda", dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406], device="cuda")
+    inv_std = 1.0 / torch.tensor([0.229, 0.224, 0.225], device="cuda")
+    z = k.nchw_to_nhwc_bf16(u8, 8, scale=1 / 255.0, mean=mean, inv_std=inv_std)
+    ref = ((u8.float() / 255.0 - mean.view(1, 3, 1, 1)) * inv_std.view(1, 3, 1, 1)).permute(0, 2, 3, 1)
+    _close(z[..., :3], ref, 1e-2, 1e-2, "u8 normalise")
+    a = torch.randn(1000 * 8 + 5, device="cuda")
+    b = torch.empty_like(a, dtype=BF16)
+    k.cast_f32_bf16(a, b)
+    assert torch.equal(b, a.to(BF16))
+    g = _rand(4096)
+    yv = _rand(4096)
+    o = k.relu_mask(g, yv, 2.0)
+    _close(o, g.float() * (yv.float() > 0) * 2.0, 1e-2, 1e-3, "relu_mask")
+
+
+def test_kernels_are_deterministic():
+    """Race screen: repeated launches must be bit-identical (cdna_hip_programming.md §5 pitfall)."""
+    k = _k()
+    torch.manual_seed(12)
+    x = _rand(4, 28, 28, 128)
+    w = _rand(256, 9 * 128, scale=0.03)
+    dy = _rand(4, 28, 28, 256, scale=0.1)
+    y0 = k.conv3x3_fprop(x, w, None, relu=True)
+    g0 = torch.empty(256, 9 * 128, device="cuda")
+    k.conv3x3_wgrad(dy, x, g0)
+    for _ in range(5):
+        assert torch.equal(k.conv3x3_fprop(x, w, None, relu=True), y0)
+        g = torch.empty_like(g0)
+        k.conv3x3_wgrad(dy, x, g)
+        assert torch.equal(g, g0)
