@@ -1,0 +1,117 @@
+"""Headline benchmark: VGG16 bf16 224x224 training images/sec (whole job), synthetic data,
+random-init weights, on N MI355X of one node (BASELINE.json "metric").
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One timed step = zero_grad + ingest (NCHW f32 -> NHWC bf16) + forward + fused softmax-xent +
+backward (weight/bias gradients for all 32 tensors, bucketed RCCL all-reduce overlapped with
+backward when N > 1) + fused SGD-momentum step on fp32 master weights.  Weak scaling: the per-GPU
+batch is fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# Stock PyTorch-ROCm (MIOpen/hipBLASLt, bf16 autocast + channels_last, torch.optim.SGD) measured on
+# one MI355X with bench/bench_stock.py — the reference publishes no numbers.
+STOCK_1GPU_BF16_IMG_S = 3352.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DTP_BENCH_BATCH", "128")))
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--grad-dtype", default=os.environ.get("DTP_BENCH_GRAD_DTYPE", "bf16"), choices=["fp32", "bf16"])
+    ap.add_argument("--lr", type=float, default=0.01)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from distributed_training_pytorch_amd.data.synthetic import DeviceBatchSource
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    from distributed_training_pytorch_amd.parallel.data_parallel import DataParallel
+
+    torch.manual_seed(0)
+    gdt = torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
+    model = VGG16(3, args.classes, True, grad_dtype=gdt).to(dev)
+    opt = FusedSGD(model, lr=args.lr, momentum=0.9, weight_decay=1e-4)
+    crit = SoftmaxCrossEntropy()
+    dp = DataParallel(model)
+    dp.train()
+    data = DeviceBatchSource(args.batch_per_gpu, args.classes, args.image_size, args.image_size,
+                             device=dev, n_distinct=2, seed=rank)
+
+    def step():
+        x, y = next(data)
+        opt.zero_grad()
+        loss = crit(dp(x), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss.detach().float().item())
+    if rank == 0:
+        global_batch = args.batch_per_gpu * world
+        value = global_batch * args.steps / dt
+        print(json.dumps({
+            "metric": "train images/sec (whole node) VGG16 bf16 224px",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": value / (STOCK_1GPU_BF16_IMG_S * world),
+            "baseline": "stock PyTorch-ROCm bf16 channels_last on 1 MI355X (%.0f img/s) x n_gpus; "
+                        "the reference publishes no numbers" % STOCK_1GPU_BF16_IMG_S,
+            "dtype": "bf16", "data": "synthetic (device-resident f32 NCHW batches, random-init weights)",
+            "final_loss": final_loss,
+            "config": {"model": "VGG16 (no BN, %d classes, 134M params)" % args.classes,
+                       "global_batch": global_batch, "image_size": args.image_size,
+                       "seq_len": None, "parallelism": "dp%d" % world,
+                       "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights",
+                       "grad_dtype": args.grad_dtype}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,312 @@
+// First VGG layer (Cin = 3): image ingest + 3x3 conv + bias + ReLU, and its weight/bias gradient.
+//
+// K = 9*Cin = 27 is far too shallow for the generic 64-deep implicit-GEMM K loop (padding Cin to
+// 64 costs 21x the MFMA work and a 128 B/pixel ingest write), so this layer gets dedicated kernels:
+//
+// fprop: a workgroup takes 256 consecutive output pixels, builds their im2col rows [256][32] bf16
+//   (k = tap*3 + c, 27 real + 5 zero) in LDS straight from the NCHW f32/bf16/u8 batch — the
+//   (x*scale - mean)/std normalisation and the NCHW->NHWC layout change are fused here, no
+//   converted copy of the input is ever written — then ONE K=32 MFMA step per 16x16 tile against
+//   the [64][32] weight image, bias+ReLU, and full-row coalesced NHWC bf16 stores.
+// wgrad: dW[64][27] = sum_p dY[p][64] (x) im2col[p][27]; reduction over pixels.  dY tiles are
+//   staged row-major by LDS-DMA and read transposed (ds_read_b64_tr_b16); the im2col tile is
+//   written transposed [k][pixel].  Column k = 27 of the im2col tile is set to 1.0, so the bias
+//   gradient (column sum of dY) drops out of the same MFMAs for free.  A persistent grid
+//   accumulates in registers over many tiles; per-workgroup partials are summed by a tiny
+//   deterministic reduce kernel (no float atomics).
+//
+// Reference parity: first nn.Conv2d(3, 64) + ReLU of model/vgg16.py:24 (cuDNN fwd / bwd-filter)
+// and the blocking H2D + dataset normalisation feeding it.
+#include "dtp_common.h"
+
+#define C1_COUT 64
+#define C1_TILE 256
+
+struct Conv1Params {
+  const void* x;          // [N][Cin][H][W]
+  const bf16_t* w;        // [64][9*Cin] bf16 (tap-major, channel-minor)
+  const float* bias;      // [64]
+  bf16_t* y;              // [N][H][W][64]
+  const float* mean;      // [Cin] or null
+  const float* inv_std;   // [Cin] or null
+  float scale;
+  int N, Cin, H, W, relu;
+  long M;                 // N*H*W
+};
+
+template <typename T> DTP_DEVINL float ld_f32(const T* p);
+template <> DTP_DEVINL float ld_f32<float>(const float* p) { return *p; }
+template <> DTP_DEVINL float ld_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <> DTP_DEVINL float ld_f32<uint8_t>(const uint8_t* p) { return (float)*p; }
+
+// im2col row of one pixel: v[k], k = tap*Cin + c  (Cin <= 3 -> 27 values), zero outside the image
+template <typename T>
+DTP_DEVINL void gather_patch(const Conv1Params& p, long pix, float* v) {
+  const long hw = (long)p.H * p.W;
+  const bool inb = pix < p.M;
+  const int n = inb ? (int)(pix / hw) : 0;
+  const int rem = inb ? (int)(pix - (long)n * hw) : 0;
+  const int h = rem / p.W, w = rem - h * p.W;
+  const T* xb = (const T*)p.x + (long)n * p.Cin * hw;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+    const bool ok = inb && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float f = 0.f;
+      if (ok && c < p.Cin) {
+        f = ld_f32<T>(xb + (long)c * hw + (long)hh * p.W + ww) * p.scale;
+        if (p.mean) f = (f - p.mean[c]) * p.inv_std[c];
+      }
+      v[t * 3 + c] = f;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fprop_kernel(const Conv1Params p) {
+  // LDS: A image [256][32] bf16 (64-B rows, 16 KiB) | W image [64][32] (4 KiB) | C image [256][64] (32 KiB)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lA = smem;
+  char* lW = smem + 256 * 64;
+  char* lC = lW + 64 * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int K = 9 * p.Cin;
+
+  {  // weights: thread -> (row = tid>>2, 8-wide k chunk = tid&3)
+    const int row = tid >> 2, ch = tid & 3;
+    u32x4_t q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k0 = ch * 8 + 2 * e;
+      const uint32_t lo = k0 < K ? p.w[row * K + k0] : 0;
+      const uint32_t hi = k0 + 1 < K ? p.w[row * K + k0 + 1] : 0;
+      q[e] = lo | (hi << 16);
+    }
+    *(u32x4_t*)(lW + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = q;
+  }
+  {  // im2col row of this thread's pixel
+    float v[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) v[k] = 0.f;
+    gather_patch<T>(p, (long)blockIdx.x * C1_TILE + tid, v);
+    const int sw = (tid >> 1) & 3;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      u32x4_t q;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q[e] = pack_bf16x2(v[ch * 8 + 2 * e], v[ch * 8 + 2 * e + 1]);
+      *(u32x4_t*)(lA + tid * 64 + ((ch ^ sw) << 4)) = q;
+    }
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fk = lane >> 4;
+  const int foff = fr * 64 + ((fk ^ ((fr >> 1) & 3)) << 4);
+  bf16x8_t xf[4], wf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8_t*)(lA + (wave * 64 + i * 16) * 64 + foff);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(lW + (j * 16) * 64 + foff);
+  const int cq = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float bv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = p.bias ? p.bias[j * 16 + cq + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc, 0, 0, 0);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = acc[e] + bv[e];
+        if (p.relu) o[e] = fmaxf(o[e], 0.f);
+      }
+      const int pl = wave * 64 + i * 16 + fr;       // pixel in tile
+      const int nl = j * 16 + cq;                   // first of 4 channels
+      u32x2_t pk;
+      pk[0] = pack_bf16x2(o[0], o[1]);
+      pk[1] = pack_bf16x2(o[2], o[3]);
+      *(u32x2_t*)(lC + pl * 128 + (((nl >> 3) ^ (pl & 7)) << 4) + ((nl >> 2) & 1) * 8) = pk;
+    }
+  }
+  __syncthreads();
+  const long m0 = (long)blockIdx.x * C1_TILE;
+  for (int id = tid; id < C1_TILE * 8; id += 256) {
+    const int pl = id >> 3, q = id & 7;
+    if (m0 + pl >= p.M) continue;
+    const u32x4_t v = *(const u32x4_t*)(lC + pl * 128 + ((q ^ (pl & 7)) << 4));
+    *(u32x4_t*)(p.y + (m0 + pl) * 64 + q * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+struct Conv1WgradParams {
+  Conv1Params c;          // x / geometry / normalisation (w, bias, y unused)
+  const char* dy;         // [M][64] bf16
+  float* partial;         // [gridDim.x][64][32] f32
+  const char* zero_page;
+  int ntiles;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams p) {
+  // LDS: dY image [256 px][64] bf16 (128-B rows, tr-read swizzle) 32 KiB | Xt image [32 k][256 px] rows of 528 B
+  constexpr int XT_RB = 528;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lD = smem;
+  char* lX = smem + 256 * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typedef __attribute__((ext_vector_type(4))) short s4;
+
+  // rows 27..31 of Xt: k = 27 is the ones column (bias gradient), the rest stay zero
+  for (int k = 27; k < 32; ++k) *(bf16_t*)(lX + k * XT_RB + tid * 2) = (k == 27) ? (bf16_t)0x3F80 : (bf16_t)0;
+
+  // dY staging geometry: 8 lanes per 128-B row, 32 rows per pass, 8 passes
+  const int drow = tid >> 3, dpc = tid & 7;
+  const int dsw = (((drow >> 1) & 1) | (((drow >> 3) & 1) << 1)) << 1;   // s_of<128>(row); row+32*i keeps it
+  const int dlc = dpc ^ dsw;
+
+  // fragment read geometry
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int krow = 8 * g4 + q;
+  const int fsw = (((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1;
+  const int sub = pp >> 1, half8 = (pp & 1) * 8;
+
+  f32x4_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const long m0 = (long)tile * C1_TILE;
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long m = m0 + drow + i * 32;
+      const char* g = m < p.c.M ? p.dy + (m * 64 + dlc * 8) * 2 : p.zero_page;
+      glds16(g, lD + wave * 1024 + i * 4096);
+    }
+    {
+      float v[27];
+      gather_patch<T>(p.c, m0 + tid, v);
+#pragma unroll
+      for (int k = 0; k < 27; ++k) *(bf16_t*)(lX + k * XT_RB + tid * 2) = f32_to_bf16(v[k]);
+    }
+    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) is emitted before the barrier)
+    // wave: pixels [64*wave, 64*wave+64) -> two 32-deep k-substeps
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int px0 = wave * 64 + ks * 32;
+      bf16x8_t af[4], bf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = ((2 * i) ^ fsw) + sub;
+        const char* a0 = lD + (px0 + krow) * 128 + (ch << 4) + half8;
+        s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+        s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 4 * 128));
+        af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        bf[j] = *(const bf16x8_t*)(lX + (j * 16 + li) * XT_RB + (px0 + 8 * g4) * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // cross-wave sum through LDS, then one partial [64][32] per workgroup
+  __syncthreads();
+  float* red = (float*)smem;   // [4 waves][64][32] f32 = 32 KiB
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)   // D row = cout (A operand), col = k (B operand)
+        red[wave * 2048 + (i * 16 + g4 * 4 + e) * 32 + j * 16 + li] = acc[i][j][e];
+  __syncthreads();
+  for (int o = tid; o < 2048; o += 256)
+    p.partial[(size_t)blockIdx.x * 2048 + o] = (red[o] + red[2048 + o]) + (red[4096 + o] + red[6144 + o]);
+}
+
+// out_w[co][k] (k < K) and out_b[co] (k == 27) = beta*old + sum_g partial[g][co][k]
+__global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, void* __restrict__ out_w,
+                                          void* __restrict__ out_b, int out_fp32, float beta_w, float beta_b) {
+  __shared__ float red[4][64];
+  const int ol = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + ol;          // 0..2047 = co*32 + k
+  float s = 0.f;
+  for (int g = grp; g < G; g += 4) s += partial[(size_t)g * 2048 + o];
+  red[grp][ol] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  s = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+  const int co = o >> 5, k = o & 31;
+  void* dst; int idx; float beta;
+  if (k < K) { dst = out_w; idx = co * K + k; beta = beta_w; }
+  else if (k == 27 && out_b) { dst = out_b; idx = co; beta = beta_b; }
+  else return;
+  if (out_fp32) {
+    float* d = (float*)dst;
+    d[idx] = (beta != 0.f ? beta * d[idx] : 0.f) + s;
+  } else {
+    bf16_t* d = (bf16_t*)dst;
+    d[idx] = f32_to_bf16((beta != 0.f ? beta * bf16_to_f32(d[idx]) : 0.f) + s);
+  }
+}
+
+static int fill_params(Conv1Params& c, const void* x, int N, int Cin, int H, int W, float scale, const float* mean,
+                       const float* inv_std) {
+  if (N <= 0 || Cin != 3 || H <= 0 || W <= 0) return -10;   // k = tap*3 + c is baked in
+  c.x = x; c.N = N; c.Cin = Cin; c.H = H; c.W = W; c.scale = scale; c.mean = mean; c.inv_std = inv_std;
+  c.M = (long)N * H * W;
+  c.w = nullptr; c.bias = nullptr; c.y = nullptr; c.relu = 0;
+  return 0;
+}
+
+extern "C" int dtp_conv1_fprop(const void* x, int in_kind, const void* w, const float* bias, void* y, int N, int Cin,
+                               int H, int W, int relu, float scale, const float* mean, const float* inv_std,
+                               hipStream_t s) {
+  Conv1Params c;
+  int rc = fill_params(c, x, N, Cin, H, W, scale, mean, inv_std);
+  if (rc) return rc;
+  c.w = (const bf16_t*)w; c.bias = bias; c.y = (bf16_t*)y; c.relu = relu;
+  const int tiles = (int)((c.M + C1_TILE - 1) / C1_TILE);
+  constexpr int lds = 256 * 64 + 64 * 64 + 256 * 128;
+  if (in_kind == 0) hipLaunchKernelGGL(conv1_fprop_kernel<float>, dim3(tiles), dim3(256), lds, s, c);
+  else if (in_kind == 1) hipLaunchKernelGGL(conv1_fprop_kernel<bf16_t>, dim3(tiles), dim3(256), lds, s, c);
+  else if (in_kind == 2) hipLaunchKernelGGL(conv1_fprop_kernel<uint8_t>, dim3(tiles), dim3(256), lds, s, c);
+  else return -11;
+  return DTP_CHECK_LAUNCH();
+}
+
+// partial: >= grid*2048 floats (grid chosen here, <= max_grid)
+extern "C" int dtp_conv1_wgrad(const void* x, int in_kind, const void* dy, void* out_w, void* out_b, float* partial,
+                               int max_grid, const void* zero_page, int N, int Cin, int H, int W, float scale,
+                               const float* mean, const float* inv_std, int out_fp32, float beta_w, float beta_b,
+                               hipStream_t s) {
+  Conv1WgradParams p;
+  int rc = fill_params(p.c, x, N, Cin, H, W, scale, mean, inv_std);
+  if (rc) return rc;
+  p.dy = (const char*)dy; p.partial = partial; p.zero_page = (const char*)zero_page;
+  p.ntiles = (int)((p.c.M + C1_TILE - 1) / C1_TILE);
+  int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
+  if (grid < 1) return -12;
+  constexpr int lds = 256 * 128 + 32 * 528;
+  if (in_kind == 0) hipLaunchKernelGGL(conv1_wgrad_kernel<float>, dim3(grid), dim3(256), lds, s, p);
+  else if (in_kind == 1) hipLaunchKernelGGL(conv1_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, p);
+  else if (in_kind == 2) hipLaunchKernelGGL(conv1_wgrad_kernel<uint8_t>, dim3(grid), dim3(256), lds, s, p);
+  else return -11;
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(32), dim3(256), 0, s, partial, grid, 9 * Cin, out_w, out_b,
+                     out_fp32, beta_w, beta_b);
+  return DTP_CHECK_LAUNCH();
+}

@@ -51,13 +51,24 @@ __global__ void colsum_pass1_kernel(const bf16_t* __restrict__ x, float* __restr
   }
 }
 
-// pass 2: out[c] = beta*out[c] + sum_b part[b][c]
+// pass 2: out[c] = beta*out[c] + sum_b part[b][c]; block = 64 columns x 4 partial-groups
 __global__ void colsum_pass2_kernel(const float* __restrict__ part, int nb, int C, int Cvalid, void* __restrict__ out,
                                     int out_fp32, float beta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Cvalid) return;
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * C + c];
+  if (c < Cvalid) {
+    int b = grp;
+    for (; b + 12 < nb; b += 16)
+      s += (part[(size_t)b * C + c] + part[(size_t)(b + 4) * C + c]) +
+           (part[(size_t)(b + 8) * C + c] + part[(size_t)(b + 12) * C + c]);
+    for (; b < nb; b += 4) s += part[(size_t)b * C + c];
+  }
+  red[grp][cl] = s;
+  __syncthreads();
+  if (grp != 0 || c >= Cvalid) return;
+  s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
   if (out_fp32) {
     float* o = (float*)out;
     o[c] = (beta != 0.f ? beta * o[c] : 0.f) + s;
@@ -72,13 +83,13 @@ extern "C" int dtp_colsum(const void* x, void* out, float* workspace, int ws_flo
                           int ld, int out_fp32, float beta, hipStream_t s) {
   if (rows <= 0 || C <= 0 || (C & 7) || (ld & 7) || Cvalid > C) return -10;
   int nb = ws_floats / C;
-  if (nb > 1024) nb = 1024;
-  if (nb > (rows + 31) / 32) nb = (rows + 31) / 32;
+  if (nb > 512) nb = 512;
+  if (nb > (rows + 63) / 64) nb = (rows + 63) / 64;
   if (nb < 1) return -11;
   const int rpb = (rows + nb - 1) / nb;
   nb = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_pass1_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, workspace, rows, C, ld, rpb);
-  hipLaunchKernelGGL(colsum_pass2_kernel, dim3((Cvalid + 255) / 256), dim3(256), 0, s, workspace, nb, C, Cvalid, out,
+  hipLaunchKernelGGL(colsum_pass2_kernel, dim3((Cvalid + 63) / 64), dim3(256), 0, s, workspace, nb, C, Cvalid, out,
                      out_fp32, beta);
   return DTP_CHECK_LAUNCH();
 }

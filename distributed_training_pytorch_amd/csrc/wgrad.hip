@@ -296,7 +296,7 @@ extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* par
   if (taps != 1 && taps != 9) return -11;
   if ((lda & 7) || (ldb & 7) || (Ntot & 7)) return -14;
   if (taps == 9) {
-    if (H < 5 || W < 5 || K % (H * W) != 0 || (C & 63) || Ntot != 9 * C || ldb != C) return -12;
+    if (H < 1 || W < 1 || K % (H * W) != 0 || (C & 63) || Ntot != 9 * C || ldb != C) return -12;
   }
   WgradParams p;
   p.dY = (const char*)dY; p.X = (const char*)X; p.partial = partial; p.out = (char*)out;

@@ -310,6 +310,45 @@ def nchw_to_nhwc_bf16(x, c_pad, scale=1.0, mean=None, inv_std=None):
     return out
 
 
+_IN_KINDS = {torch.float32: 0, BF16: 1, torch.uint8: 2}
+
+
+def conv1_fprop(x, w, bias, relu=True, scale=1.0, mean=None, inv_std=None):
+    """First layer: NCHW f32/bf16/u8 [N,3,H,W] -> NHWC bf16 [N,H,W,64] = relu(conv3x3(norm(x)) + b)."""
+    if x.dtype not in _IN_KINDS or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError("conv1_fprop: need contiguous CUDA NCHW f32/bf16/u8 with 3 channels")
+    _need(w, BF16, "w")
+    if w.numel() != 64 * 27:
+        raise ValueError("conv1_fprop: weight must be [64, 27]")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    N, Cin, H, W = x.shape
+    y = torch.empty((N, H, W, 64), dtype=BF16, device=x.device)
+    rc = _lib.hip().dtp_conv1_fprop(ptr(x), _IN_KINDS[x.dtype], ptr(w), ptr(bias), ptr(y), N, Cin, H, W, int(relu),
+                                    float(scale), ptr(mean), ptr(inv_std), stream())
+    check(rc, "conv1_fprop")
+    return y
+
+
+def conv1_wgrad(x, dy, out_w, out_b, beta_w=0.0, beta_b=0.0, scale=1.0, mean=None, inv_std=None):
+    """out_w[64, 27] and out_b[64] (same dtype, f32 or bf16) from dy NHWC bf16 [N,H,W,64] and the raw input."""
+    if x.dtype not in _IN_KINDS or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError("conv1_wgrad: bad x")
+    _need(dy, BF16, "dy")
+    N, Cin, H, W = x.shape
+    if tuple(dy.shape) != (N, H, W, 64) or out_w.numel() != 64 * 27 or out_b.numel() != 64:
+        raise ValueError("conv1_wgrad: bad shapes")
+    if out_w.dtype != out_b.dtype or out_w.dtype not in (torch.float32, BF16):
+        raise ValueError("conv1_wgrad: bad output dtype")
+    max_grid = 3 * N_CU
+    partial = workspace.get("conv1_partial", max_grid * 2048, torch.float32, x.device)
+    rc = _lib.hip().dtp_conv1_wgrad(ptr(x), _IN_KINDS[x.dtype], ptr(dy), ptr(out_w), ptr(out_b), ptr(partial),
+                                    max_grid, ptr(workspace.zero_page(x.device)), N, Cin, H, W, float(scale),
+                                    ptr(mean), ptr(inv_std), int(out_w.dtype == torch.float32), float(beta_w),
+                                    float(beta_b), stream())
+    check(rc, "conv1_wgrad")
+
+
 def cast_f32_bf16(src, dst):
     _need(src, torch.float32, "src")
     _need(dst, BF16, "dst")

@@ -121,16 +121,24 @@ class Conv3x3(FusedLayer):
 
 # =============================================================================== first conv (Cin = 3)
 class _ConvFirstFn(torch.autograd.Function):
-    """Image ingest + first convolution.  The NCHW f32/bf16/u8 batch is converted to NHWC bf16 with
-    the channel axis zero-padded to the 64-wide K chunk of the implicit-GEMM kernel."""
+    """Image ingest + first convolution (csrc/conv_first.hip): the NCHW f32/bf16/u8 batch is
+    normalised and im2col'ed inside the kernel; the weight AND bias gradient come out of one
+    persistent kernel.  Inputs with Cin != 3 take the generic kernels on a channel-padded copy."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, layer):
         arena = _arena_of(layer)
-        xp = K.nchw_to_nhwc_bf16(x.contiguous(), layer.c_pad, layer.in_scale, layer.in_mean, layer.in_inv_std)
+        x = x.contiguous()
+        ctx.layer = layer
+        ctx.fast = x.shape[1] == 3
+        if ctx.fast:
+            y = K.conv1_fprop(x, arena.lp(weight), bias.detach(), layer.relu, layer.in_scale, layer.in_mean,
+                              layer.in_inv_std)
+            ctx.save_for_backward(x, y, weight, bias)
+            return y
+        xp = K.nchw_to_nhwc_bf16(x, layer.c_pad, layer.in_scale, layer.in_mean, layer.in_inv_std)
         wp = layer._cached("w_pad", lambda: layer._pad_weight(arena.lp(weight)))
         y = K.conv3x3_fprop(xp, wp, bias.detach(), relu=layer.relu)
-        ctx.layer = layer
         ctx.save_for_backward(xp, y, weight, bias)
         return y
 
@@ -143,16 +151,20 @@ class _ConvFirstFn(torch.autograd.Function):
         if layer.relu and not layer.grad_premasked:
             dy = K.relu_mask(dy, y)
         Co, Ci = weight.shape[0], weight.shape[1]
-        gpad = K.workspace.get("convfirst_gw", Co * 9 * layer.c_pad, torch.float32, dy.device)
-        gpad = gpad[:Co * 9 * layer.c_pad].view(Co, 9 * layer.c_pad)
-        K.conv3x3_wgrad(dy, xp, gpad, beta=0.0)
-        g = gpad.view(Co, 9, layer.c_pad)[:, :, :Ci]
-        dst = arena.grad(weight).view(Co, 9, Ci)
-        if arena.grad_beta(weight) == 0.0:
-            dst.copy_(g)
+        if ctx.fast:
+            K.conv1_wgrad(xp, dy, arena.grad(weight), arena.grad(bias), arena.grad_beta(weight),
+                          arena.grad_beta(bias), layer.in_scale, layer.in_mean, layer.in_inv_std)
         else:
-            dst.add_(g)
-        K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            gpad = K.workspace.get("convfirst_gw", Co * 9 * layer.c_pad, torch.float32, dy.device)
+            gpad = gpad[:Co * 9 * layer.c_pad].view(Co, 9 * layer.c_pad)
+            K.conv3x3_wgrad(dy, xp, gpad, beta=0.0)
+            g = gpad.view(Co, 9, layer.c_pad)[:, :, :Ci]
+            dst = arena.grad(weight).view(Co, 9, Ci)
+            if arena.grad_beta(weight) == 0.0:
+                dst.copy_(g)
+            else:
+                dst.add_(g)
+            K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
         return None, None, None, None

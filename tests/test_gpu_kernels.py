@@ -340,3 +340,42 @@ def test_kernels_are_deterministic():
         g = torch.empty_like(g0)
         k.conv3x3_wgrad(dy, x, g)
         assert torch.equal(g, g0)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16), (3, 9, 13), (1, 224, 224), (5, 7, 7)])
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.uint8])
+def test_conv1_fprop_wgrad(shape, in_dtype):
+    """Dedicated first-layer kernels (fused ingest/normalise + conv + bias + ReLU; wgrad + bias grad)."""
+    k = _k()
+    torch.manual_seed(13)
+    N, H, W = shape
+    mean = torch.tensor([0.485, 0.456, 0.406], device="cuda")
+    inv_std = 1.0 / torch.tensor([0.229, 0.224, 0.225], device="cuda")
+    if in_dtype == torch.uint8:
+        x = torch.randint(0, 256, (N, 3, H, W), device="cuda", dtype=torch.uint8)
+        xn = (x.float() / 255.0 - mean.view(1, 3, 1, 1)) * inv_std.view(1, 3, 1, 1)
+        kw = dict(scale=1 / 255.0, mean=mean, inv_std=inv_std)
+    else:
+        x = torch.randn(N, 3, H, W, device="cuda")
+        xn = x
+        kw = {}
+    xn = xn.to(BF16).float()                      # the kernel rounds the normalised input to bf16
+    w = _rand(64, 27, scale=(2.0 / 27) ** 0.5)
+    b = torch.randn(64, device="cuda")
+    y = k.conv1_fprop(x, w, b, relu=True, **kw)
+    w4 = w.float().view(64, 3, 3, 3).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = F.conv2d(xn, w4, b, padding=1)
+    _close(y, yr.relu().permute(0, 2, 3, 1), 2e-2, 2e-2, "conv1 fprop")
+    dy = _rand(N, H, W, 64, scale=0.1)
+    for dt in (torch.float32, BF16):
+        gw = torch.full((64, 27), 3.0, device="cuda", dtype=dt)
+        gb = torch.full((64,), 3.0, device="cuda", dtype=dt)
+        k.conv1_wgrad(x, dy, gw, gb, **kw)
+        (gref,) = torch.autograd.grad(yr, w4, dy.float().permute(0, 3, 1, 2), retain_graph=True)
+        gref = gref.permute(0, 2, 3, 1).reshape(64, 27)
+        bref = dy.float().sum((0, 1, 2))
+        _close(gw, gref, 2e-2, 2e-2 * gref.abs().max().item(), "conv1 wgrad")
+        _close(gb, bref, 2e-2, 2e-2 * bref.abs().max().item(), "conv1 bgrad")
+        k.conv1_wgrad(x, dy, gw, gb, beta_w=1.0, beta_b=1.0, **kw)
+        _close(gw, 2 * gref, 3e-2, 3e-2 * gref.abs().max().item(), "conv1 wgrad acc")
+        _close(gb, 2 * bref, 3e-2, 3e-2 * bref.abs().max().item(), "conv1 bgrad acc")

@@ -1,0 +1,170 @@
+"""End-to-end single-GPU checks of the fused VGG16 path (SURVEY.md §4.2 'End-to-end single GPU'):
+GPU (HIP kernels, bf16) forward/backward against the CPU fp32 reference path of the *same*
+modules and weights; loss decreases on a learnable synthetic set; checkpoint round trip."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(size=32, classes=3, seed=0, grad_dtype=torch.float32):
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    torch.manual_seed(seed)
+    cpu = VGG16(3, classes, True, dropout=0.0)
+    gpu = VGG16(3, classes, True, dropout=0.0, grad_dtype=grad_dtype)
+    gpu.load_state_dict(cpu.state_dict())
+    return cpu, gpu.to("cuda")
+
+
+def test_native_library_is_loaded():
+    from distributed_training_pytorch_amd import _lib
+    _lib.hip()
+    maps = open("/proc/self/maps").read()
+    assert "libdtp_hip.so" in maps
+
+
+class _RoundBF16(torch.autograd.Function):
+    """Straight-through bf16 rounding of activations (forward) and their gradients (backward):
+    the rounding points of the fused kernels, so ReLU masks agree with the GPU path."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def _emulated_reference(sd, x, y):
+    """fp32 torch ops on bf16-rounded weights/activations; returns (logits, loss, grads by name)."""
+    import torch.nn.functional as F
+    rb = _RoundBF16.apply
+    params = {}
+
+    def P(name, lowp=True):
+        t = sd[name].detach().cuda().float()
+        if lowp:
+            t = t.bfloat16().float()
+        t.requires_grad_(True)
+        params[name] = t
+        return t
+
+    h = rb(x)
+    for b, n in enumerate([2, 2, 3, 3, 3]):
+        for i in range(n):
+            w, bias = P("backbone.%d.conv.%d.weight" % (b, 2 * i)), P("backbone.%d.conv.%d.bias" % (b, 2 * i), False)
+            h = rb(F.relu(F.conv2d(h, w, bias, padding=1)))
+        h = F.max_pool2d(h, 2, 2)
+    h = rb(torch.flatten(F.adaptive_avg_pool2d(h, (7, 7)), 1))
+    h = rb(F.relu(F.linear(h, P("linear1.weight"), P("linear1.bias", False))))
+    h = rb(F.relu(F.linear(h, P("linear2.weight"), P("linear2.bias", False))))
+    logits = F.linear(h, P("linear3.weight"), P("linear3.bias", False))
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    return logits.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
+
+
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("size", [64, 96])
+def test_forward_backward_matches_reference(grad_dtype, size):
+    """GPU (HIP, bf16) vs (a) an fp32 torch reference with the same bf16 rounding points — tight —
+    and (b) the pure fp32 CPU path of the same modules — loose: in a ReLU net ~1% of the masks flip
+    under bf16 noise, which decorrelates deep-layer gradients (cos ~0.93 at conv1_1, measured)."""
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    cpu, gpu = _models(grad_dtype=grad_dtype)
+    torch.manual_seed(1)
+    x = torch.randn(8, 3, size, size)
+    y = torch.randint(0, 3, (8,))
+    crit = SoftmaxCrossEntropy()
+    cpu.train(); gpu.train()
+    out_c = cpu(x)
+    loss_c = crit(out_c, y)
+    loss_c.backward()
+    out_g = gpu(x.cuda())
+    loss_g = crit(out_g, y.cuda())
+    loss_g.backward()
+    torch.cuda.synchronize()
+    assert out_g.dtype == torch.float32 and out_g.shape == out_c.shape
+    scale = out_c.abs().max().item()
+    assert (out_g.cpu() - out_c).abs().max().item() < 0.05 * scale + 1e-3
+    assert abs(loss_g.item() - loss_c.item()) < 2e-2
+    ref_logits, ref_loss, ref_grads = _emulated_reference(cpu.state_dict(), x.cuda(), y.cuda())
+    assert (out_g - ref_logits).abs().max().item() < 0.01 * scale + 1e-4
+    a = gpu.param_arena
+    gp = dict(gpu.named_parameters())
+    cos = torch.nn.functional.cosine_similarity
+    for name, pc in cpu.named_parameters():
+        gg = a._logical_view(a.flat_grad, a.index[id(gp[name])]).float()
+        ge = ref_grads[name]
+        c_emu = cos(gg.flatten(), ge.flatten(), dim=0).item()
+        ratio = gg.norm().item() / (ge.norm().item() + 1e-20)
+        assert c_emu > 0.95 and 0.95 < ratio < 1.05, "%s: vs emulated ref cos %.4f norm ratio %.4f" % (name, c_emu, ratio)
+        c_cpu = cos(gg.flatten().cpu(), pc.grad.flatten(), dim=0).item()
+        assert c_cpu > 0.85, "%s: vs fp32 CPU cos %.4f" % (name, c_cpu)
+
+
+def test_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):
+    from distributed_training_pytorch_amd.data.synthetic import SyntheticImageDataset
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    from distributed_training_pytorch_amd.utils import checkpoint as ckpt
+    torch.manual_seed(0)
+    ds = SyntheticImageDataset(64, 3, 32, 32, seed=0, signal=2.0)
+    xs = torch.stack([ds[i][0] for i in range(64)]).cuda()
+    ys = torch.tensor([ds[i][1] for i in range(64)]).cuda()
+    model = VGG16(3, 3, True).cuda().train()
+    opt = FusedSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    crit = SoftmaxCrossEntropy()
+    losses = []
+    for it in range(40):
+        opt.zero_grad()
+        loss = crit(model(xs), ys)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < 0.5 * losses[0], losses[::5]
+    # checkpoint in the reference schema, reload into a fresh model: identical logits in eval
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [50, 100, 200], gamma=0.1)
+    path = str(tmp_path / "weights" / "last.pth")
+    ckpt.save_snapshot(path, 3, model, opt, sched)
+    snap = ckpt.load_snapshot(path)
+    assert set(ckpt.REQUIRED_KEYS) <= set(snap.keys())
+    assert snap["model_state_dict"]["backbone.0.conv.0.weight"].shape == (64, 3, 3, 3)
+    assert snap["model_state_dict"]["backbone.0.conv.0.weight"].is_contiguous()
+    m2 = VGG16(3, 3, True)
+    m2.load_state_dict(snap["model_state_dict"])
+    m2 = m2.cuda().eval()
+    model.eval()
+    with torch.no_grad():
+        assert torch.equal(model(xs), m2(xs))
+    opt2 = FusedSGD(m2, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    opt2.load_state_dict(snap["optimizer_state_dict"])
+    assert torch.equal(opt2._flat_state["momentum_buffer"], opt._flat_state["momentum_buffer"])
+
+
+def test_grad_accumulation_equals_big_batch():
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    _, gpu = _models(seed=3)
+    crit = SoftmaxCrossEntropy()
+    torch.manual_seed(4)
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 3, (16,), device="cuda")
+    a = gpu.param_arena
+    a.zero_grad()
+    crit(gpu(x), y).backward()
+    ref = a.flat_grad.clone()
+    a.zero_grad()
+    (crit(gpu(x[:8]), y[:8]) / 2).backward()
+    (crit(gpu(x[8:]), y[8:]) / 2).backward()
+    torch.cuda.synchronize()
+    err = (a.flat_grad - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+    assert err < 0.03, err
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
