@@ -22,6 +22,7 @@
 // cuBLAS linear that the reference reaches through
 // model/vgg16.py:9-13,71-79.
 #include "dtp_common.h"
+#include <type_traits>
 
 struct IgemmParams {
   const char* A;
@@ -44,7 +45,7 @@ struct IgemmParams {
   int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool TAPS9>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmParams p) {
   constexpr int T = WGM * WGN * 64;
   constexpr int RP = T / 8;          // tile rows covered by one staging pass (8 lanes per 128-B row)
@@ -172,14 +173,94 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     }
   };
 
+  // Software-pipelined K-step (PIPE == 1): the wave's tile is cut into sub-steps
+  // (k-substep x m-half); fragments of sub-step s+1 are read from LDS while the MFMAs of sub-step s
+  // issue, and the LDS-DMA of the NEXT K-step (address selects + global_load_lds) is spread over
+  // the sub-steps so its VALU/SALU work hides under the matrix pipe instead of preceding it.
+  auto step = [&](int kt, int buf, auto pf_tag) {
+    constexpr bool PF = decltype(pf_tag)::value;
+    constexpr int MH = MI >= 2 ? 2 : 1;
+    constexpr int MIH = MI / MH;
+    constexpr int NSUB = 2 * MH;
+    constexpr int NP = AP + BP;
+    const char* base = smem + buf * STAGE;
+    int tap = 0, cc = kt + 1;
+    long koffA = 0, koffB = 0;
+    char* lA = smem + (buf ^ 1) * STAGE + wave * (8 * 128);
+    char* lB = lA + BM * 128;
+    if (PF) {
+      if (TAPS9) {
+        tap = (kt + 1) / cchunks;
+        cc = (kt + 1) - tap * cchunks;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        koffA = ((long)(dy * p.W + dx) * p.C + cc * 64) * 2;
+        koffB = ((long)tap * p.C + cc * 64) * 2;
+      } else {
+        koffA = (long)cc * 128;
+        koffB = (long)cc * 128;
+      }
+    }
+    bf16x8_t xa[2][MIH], wb[2][NI];
+#pragma unroll
+    for (int i = 0; i < MIH; ++i) xa[0][i] = *(const bf16x8_t*)(base + a_base + i * 2048 + foff0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) wb[0][j] = *(const bf16x8_t*)(base + b_base + j * 2048 + foff0);
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      const int ks = s / MH, mh = s % MH;
+      if (s + 1 < NSUB) {
+        const int ks1 = (s + 1) / MH, mh1 = (s + 1) % MH;
+        const int fo1 = ks1 ? foff1 : foff0;
+#pragma unroll
+        for (int i = 0; i < MIH; ++i)
+          xa[(s + 1) & 1][i] = *(const bf16x8_t*)(base + a_base + (mh1 * MIH + i) * 2048 + fo1);
+        if (ks1 != ks) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) wb[ks1 & 1][j] = *(const bf16x8_t*)(base + b_base + j * 2048 + fo1);
+        }
+      }
+      if (PF) {
+#pragma unroll
+        for (int pc = (s * NP) / NSUB; pc < ((s + 1) * NP) / NSUB; ++pc) {
+          if (pc < AP) {
+            const bool ok = (amask[pc] >> tap) & 1u;
+            const char* g = ok ? aptr[pc] + koffA : p.zero_page;
+            glds16(g, lA + pc * RP * 128);
+          } else {
+            const char* g = bok[pc - AP] ? bptr[pc - AP] + koffB : p.zero_page;
+            glds16(g, lB + (pc - AP) * RP * 128);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MIH; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[mh * MIH + i][j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks & 1][j], xa[s & 1][i], acc[mh * MIH + i][j], 0, 0, 0);
+    }
+  };
+
   // ---------------- main loop: 2 LDS stages, one barrier per K-step
   if (kbeg < kend) stage(kbeg, 0);
   int buf = 0;
-  for (int kt = kbeg; kt < kend; ++kt) {
-    __syncthreads();   // stage kt landed everywhere; everyone is done reading the other buffer
-    if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
-    compute(buf);
-    buf ^= 1;
+  if (PIPE == 0) {
+    for (int kt = kbeg; kt < kend; ++kt) {
+      __syncthreads();   // stage kt landed everywhere; everyone is done reading the other buffer
+      if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
+      compute(buf);
+      buf ^= 1;
+    }
+  } else {
+    for (int kt = kbeg; kt < kend - 1; ++kt) {
+      __syncthreads();
+      step(kt, buf, std::true_type{});
+      buf ^= 1;
+    }
+    if (kbeg < kend) {
+      __syncthreads();
+      step(kend - 1, buf, std::false_type{});
+    }
   }
 
   // ---------------- epilogue
@@ -301,14 +382,14 @@ __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ partial, in
 }
 
 // -------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool TAPS9>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE>
 static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Ncols + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9>;
+  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -2;
@@ -341,14 +422,23 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   if (nsplit > 1 && partial == nullptr) return -15;
   int rc;
   const bool t9 = taps == 9;
-  switch (cfg) {
-    case 0: rc = t9 ? launch_cfg<256, 256, 2, 4, true>(p, nsplit, stream) : launch_cfg<256, 256, 2, 4, false>(p, nsplit, stream); break;
-    case 1: rc = t9 ? launch_cfg<256, 128, 4, 2, true>(p, nsplit, stream) : launch_cfg<256, 128, 4, 2, false>(p, nsplit, stream); break;
-    case 2: rc = t9 ? launch_cfg<256, 64, 4, 1, true>(p, nsplit, stream) : launch_cfg<256, 64, 4, 1, false>(p, nsplit, stream); break;
-    case 3: rc = t9 ? launch_cfg<128, 128, 2, 2, true>(p, nsplit, stream) : launch_cfg<128, 128, 2, 2, false>(p, nsplit, stream); break;
-    case 4: rc = t9 ? launch_cfg<128, 64, 2, 1, true>(p, nsplit, stream) : launch_cfg<128, 64, 2, 1, false>(p, nsplit, stream); break;
+#define DTP_IG(BM_, BN_, WGM_, WGN_, PIPE_)                                     \
+  (t9 ? launch_cfg<BM_, BN_, WGM_, WGN_, true, PIPE_>(p, nsplit, stream)        \
+      : launch_cfg<BM_, BN_, WGM_, WGN_, false, PIPE_>(p, nsplit, stream))
+  switch (cfg) {   // cfg 0-4: plain 2-stage loop; 8-12: software-pipelined K-step
+    case 0: rc = DTP_IG(256, 256, 2, 4, 0); break;
+    case 1: rc = DTP_IG(256, 128, 4, 2, 0); break;
+    case 2: rc = DTP_IG(256, 64, 4, 1, 0); break;
+    case 3: rc = DTP_IG(128, 128, 2, 2, 0); break;
+    case 4: rc = DTP_IG(128, 64, 2, 1, 0); break;
+    case 8: rc = DTP_IG(256, 256, 2, 4, 1); break;
+    case 9: rc = DTP_IG(256, 128, 4, 2, 1); break;
+    case 10: rc = DTP_IG(256, 64, 4, 1, 1); break;
+    case 11: rc = DTP_IG(128, 128, 2, 2, 1); break;
+    case 12: rc = DTP_IG(128, 64, 2, 1, 1); break;
     default: return -16;
   }
+#undef DTP_IG
   if (rc != 0) return rc;
   if (nsplit > 1) {
     const size_t total = (size_t)M * Ncols;

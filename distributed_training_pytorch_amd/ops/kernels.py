@@ -15,7 +15,8 @@ BF16 = torch.bfloat16
 N_CU = 256
 
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
-IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64)}
+IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64),
+               8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
 WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
@@ -40,10 +41,14 @@ def pick_igemm(M, N, ksteps):
     """Largest tile that still yields >= ~2 workgroups per CU; split-K when the grid is tiny."""
     if "igemm" in _overrides:
         return _overrides["igemm"](M, N, ksteps)
+    # measured on MI355X (bench/bench_kernels.py --sweep, batch 128, random data): the
+    # software-pipelined 256x256 / 256x128 variants (cfg 8 / 9) win on wide outputs with many
+    # rows; 128x128 at two workgroups per CU (cfg 3) wins on mid-sized grids; 64-wide outputs
+    # are LDS-fill bound and prefer the plain 256x64 loop (cfg 2).
     if N > 128:
-        order = [0, 3]
+        order = [8, 3]
     elif N > 64:
-        order = [1, 3]
+        order = [9, 3] if M >= (1 << 20) else [3]
     else:
         order = [2, 4]
     cfg = order[-1]

@@ -90,8 +90,11 @@ class FusedSGD(_FusedBase):
     def __init__(self, model, lr=0.1, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         if nesterov and (momentum <= 0 or dampening != 0):
             raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        # maximize/foreach/differentiable/fused: inert keys of torch.optim.SGD's group schema, kept so
+        # that a checkpoint written here resumes a stock torch.optim.SGD and vice versa
         super().__init__(model, dict(lr=lr, momentum=momentum, dampening=dampening,
-                                     weight_decay=weight_decay, nesterov=nesterov))
+                                     weight_decay=weight_decay, nesterov=nesterov, maximize=False,
+                                     foreach=None, differentiable=False, fused=None))
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

@@ -1,0 +1,128 @@
+"""Worker for the multi-process CPU/gloo tests (launched by tests/test_dist_gloo.py through
+``python -m torch.distributed.run``).  Each scenario asserts inside the ranks and writes
+``ok.<rank>`` files; a failing rank exits non-zero, which fails the launcher."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from distributed_training_pytorch_amd.parallel import comm, env as penv  # noqa: E402
+from distributed_training_pytorch_amd.parallel.data_parallel import DataParallel  # noqa: E402
+
+
+def _allclose_across_ranks(t, atol=0.0):
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float((hi - lo).abs().max()) <= atol
+
+
+def scenario_reducer(out):
+    """Bucketed reducer == single-process large-batch gradient; no_sync accumulates; params stay
+    identical across ranks."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(1234)                      # same init everywhere, then perturb non-zero ranks
+    net = nn.Sequential(nn.Linear(16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 5))
+    ref = nn.Sequential(nn.Linear(16, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 5))
+    ref.load_state_dict(net.state_dict())
+    if rank != 0:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(1.0)                      # DataParallel must overwrite this with rank 0's values
+    dp = DataParallel(net, bucket_cap_mb=0.004, first_bucket_mb=0.001)
+    assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(p, q), "broadcast of initial parameters failed"
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(8 * world, 16, generator=g)
+    Y = torch.randint(0, 5, (8 * world,), generator=g)
+    xs, ys = X[rank::world], Y[rank::world]
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9)
+    for it in range(3):
+        opt.zero_grad(set_to_none=(it % 2 == 0))
+        nn.functional.cross_entropy(dp(xs), ys).backward()
+        ropt.zero_grad()
+        nn.functional.cross_entropy(ref(X), Y).backward()     # mean over the global batch
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-6), "averaged gradient != large-batch gradient"
+        opt.step()
+        ropt.step()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, atol=1e-6)
+        assert _allclose_across_ranks(p.detach())
+    # gradient accumulation: two micro-batches, sync only on the second
+    opt.zero_grad(set_to_none=False)
+    launched = dp.reducer.stats["launched"]
+    with dp.no_sync():
+        (nn.functional.cross_entropy(dp(xs[:4]), ys[:4]) / 2).backward()
+    assert dp.reducer.stats["launched"] == launched, "no_sync must not communicate"
+    (nn.functional.cross_entropy(dp(xs[4:]), ys[4:]) / 2).backward()
+    ropt.zero_grad()
+    Xs = torch.cat([X[r::world][:4] for r in range(world)] + [X[r::world][4:] for r in range(world)])
+    Ys = torch.cat([Y[r::world][:4] for r in range(world)] + [Y[r::world][4:] for r in range(world)])
+    nn.functional.cross_entropy(ref(Xs), Ys).backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-6), "accumulated gradient mismatch"
+
+
+def scenario_trainer(out):
+    """The real ExampleTrainer on VGG16 with synthetic 32x32x3 data (BASELINE.json config 1)."""
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+    from distributed_training_pytorch_amd.utils.logger import Logger
+    rank = dist.get_rank()
+    save = os.path.join(out, "runs")
+    kw = dict(train_path="synthetic:32", val_path="synthetic:10", labels=["a", "b", "c"], height=32, width=32,
+              batch_size=8, pin_memory=True, have_validate=True, save_best_for=("accuracy", "geq"),
+              save_period=1, save_folder=save, progress=False, lr=0.01, milestones=(1, 5))
+    logger = Logger("T", file=os.path.join(save, "logfile.log"))
+    tr = ExampleTrainer(max_epoch=2, snapshot_path=None, logger=logger, **kw)
+    assert tr.local_batch_size == 4 and tr.world_size == 2
+    tr.train()
+    flat = tr.raw_model.param_arena.flat_master
+    assert _allclose_across_ranks(flat.detach().clone()), "parameters diverged across ranks"
+    comm.barrier()
+    files = sorted(os.listdir(os.path.join(save, "weights")))
+    assert files == ["best.pth", "last.pth"], files
+    snap = torch.load(os.path.join(save, "weights", "last.pth"), map_location="cpu", weights_only=False)
+    assert snap["epoch"] == 2 and "best_fitness" in snap
+    assert abs(tr.scheduler.get_last_lr()[0] - 0.001) < 1e-12          # one milestone passed
+    # resume: continues at epoch 2 with the decayed LR and the stored best fitness (quirks #4, #7)
+    tr2 = ExampleTrainer(max_epoch=3, snapshot_path=os.path.join(save, "weights", "last.pth"), logger=logger, **kw)
+    assert tr2.cur_epoch == 2
+    assert abs(tr2.scheduler.get_last_lr()[0] - 0.001) < 1e-12
+    assert tr2.best_fitness["epoch"] is not None
+    assert torch.equal(tr2.raw_model.param_arena.flat_master, flat)
+    tr2.train()
+    if rank == 0:
+        log = open(os.path.join(save, "logfile.log")).read()
+        for needle in ("Epoch 3/3", "VALIDATE RESULTS", "The BEST model is at EPOCH", "THE NEXT LEARNING RATE VALUE IS",
+                       "TOTAL LOCAL TRAINING LOSS", "Saved model at epoch 3!", "Finished!"):
+            assert needle in log, needle
+    assert not os.path.exists(os.path.join(save, "logfile.log.rank1"))
+
+
+def scenario_fault(out):
+    """Kill-a-rank: rank 1 dies at global step 1; rank 0 must fail fast (timeout), not hang."""
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+    os.environ["FAULT_INJECT_STEP"] = "1"
+    os.environ["FAULT_INJECT_RANK"] = "1"
+    tr = ExampleTrainer(train_path="synthetic:32", val_path="synthetic:8", labels=["a", "b", "c"], height=32,
+                        width=32, max_epoch=1, batch_size=8, pin_memory=False, have_validate=False,
+                        save_period=1, save_folder=os.path.join(out, "runs"), progress=False, lr=0.01)
+    tr.train()
+
+
+if __name__ == "__main__":
+    scenario, out = sys.argv[1], sys.argv[2]
+    penv.ddp_setup("gloo", timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
+    {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault}[scenario](out)
+    comm.barrier()
+    open(os.path.join(out, "ok.%d" % dist.get_rank()), "w").write("ok")
+    penv.destroy_process()

@@ -65,7 +65,7 @@ def test_conv3x3_fprop(shape):
     _close(y2, _ref_conv(x, w, None, False), 2e-2, 2e-2, "fprop-nobias%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12])
 def test_conv3x3_fprop_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(1)

@@ -1,0 +1,281 @@
+"""CPU unit tier: logger, sampler parity with torch's DistributedSampler, bucket
+planning, snapshot schema, fused optimizers vs torch.optim, VGG16 state_dict compatibility,
+config validation, trainer semantics (best tracking, LR schedule, resume)."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+from distributed_training_pytorch_amd.models.vgg16 import VGG16
+from distributed_training_pytorch_amd.ops.optim import FusedAdamW, FusedSGD
+from distributed_training_pytorch_amd.parallel.reducer import BucketedReducer, plan_buckets
+from distributed_training_pytorch_amd.parallel.sampler import ShardedSampler
+from distributed_training_pytorch_amd.utils import checkpoint as ckpt
+from distributed_training_pytorch_amd.utils.logger import Logger
+
+
+# ------------------------------------------------------------------------------------ logger
+def test_logger_format_levels_and_parent_dir(tmp_path):
+    path = tmp_path / "runs" / "sub" / "logfile.log"       # parent does not exist (quirk #21)
+    lg = Logger("VGG16-test", str(path), rank=0)
+    lg.log("hello", "info")
+    lg.log("careful", "warning")
+    lg.log("bad", "error")
+    lg.log("other", "whatever")                              # anything else -> INFO
+    lg.close()
+    lines = path.read_text().strip().splitlines()
+    assert len(lines) == 4
+    assert " - VGG16-test - INFO - hello" in lines[0]
+    assert " - WARNING - careful" in lines[1] and " - ERROR - bad" in lines[2] and " - INFO - other" in lines[3]
+    import re
+    assert re.match(r"^\d{4}-\d{2}-\d{2}   \d{2}:\d{2}:\d{2} - ", lines[0])   # three spaces, like the reference
+
+
+def test_logger_rank_filter(tmp_path):
+    path = tmp_path / "log.txt"
+    lg0 = Logger("L", str(path), rank=0)
+    lg1 = Logger("L", str(path), rank=1)                     # silent, must not truncate rank 0's file
+    lg0.log("from0", "info")
+    lg1.log("from1", "info")
+    lg0.close(); lg1.close()
+    txt = path.read_text()
+    assert "from0" in txt and "from1" not in txt
+    lg2 = Logger("L", str(path), rank=2, all_ranks=True)
+    lg2.log("from2", "info")
+    lg2.close()
+    assert "from2" in open(str(path) + ".rank2").read()
+
+
+# ------------------------------------------------------------------------------------ sampler
+@pytest.mark.parametrize("n,world", [(10, 2), (11, 4), (3, 4), (64, 8), (1, 1)])
+def test_sampler_matches_torch_distributed_sampler(n, world):
+    from torch.utils.data.distributed import DistributedSampler
+    ds = list(range(n))
+    for epoch in (0, 1, 5):
+        seen = []
+        for r in range(world):
+            ref = DistributedSampler(ds, num_replicas=world, rank=r, shuffle=True, seed=0)
+            ref.set_epoch(epoch)
+            mine = ShardedSampler(n, r, world, shuffle=True, seed=0)
+            mine.set_epoch(epoch)
+            assert list(mine) == list(ref)
+            assert len(mine) == len(ref)
+            seen += list(mine)
+        assert set(seen) == set(range(n))                    # covers the dataset
+        assert len(seen) == math.ceil(n / world) * world     # padded to a multiple of world
+
+
+def test_sampler_epoch_reshuffles_and_unpadded_eval_shards():
+    a = ShardedSampler(100, 0, 2); a.set_epoch(0)
+    b = ShardedSampler(100, 0, 2); b.set_epoch(1)
+    assert list(a) != list(b)
+    parts = [list(ShardedSampler(11, r, 4, shuffle=False, pad=False)) for r in range(4)]
+    flat = sorted(sum(parts, []))
+    assert flat == list(range(11))                           # disjoint, no duplicates
+    with pytest.raises(ValueError):
+        ShardedSampler(10, 2, 2)
+
+
+# ------------------------------------------------------------------------------------ bucket plan
+def test_plan_buckets_reverse_order_caps_and_split():
+    numels = [100, 200, 5000, 50, 10]          # registration order
+    plan = plan_buckets(numels, 4, first_cap_bytes=100, cap_bytes=4000, split_large_bytes=8000)
+    flat = [(i, s, e) for b in plan for (i, s, e) in b]
+    # every element of every param exactly once
+    cover = {}
+    for i, s, e in flat:
+        cover.setdefault(i, []).append((s, e))
+    for i, n in enumerate(numels):
+        segs = sorted(cover[i])
+        assert segs[0][0] == 0 and segs[-1][1] == n
+        assert all(segs[k][1] == segs[k + 1][0] for k in range(len(segs) - 1))
+    assert plan[0][0][0] == 4                   # last-registered parameter goes first
+    assert sum(1 for b in plan for (i, _, _) in b if i == 2) == 3   # 20000 B param split into 3 chunks
+    order = [i for b in plan for (i, _, _) in b]
+    assert order == sorted(order, reverse=True)
+
+
+def test_vgg16_bucket_plan_matches_survey():
+    m = VGG16(3, 3, False)
+    numels = [p.numel() for p in m.parameters()]
+    plan = plan_buckets(numels, 4, 1 << 20, 25 << 20)       # DDP-like caps
+    sizes = [sum(e - s for _, s, e in b) * 4 / 2 ** 20 for b in plan]
+    assert abs(sum(sizes) - 134272835 * 4 / 2 ** 20) < 1e-3
+    assert max(sizes) > 390                                  # linear1.weight dominates (411 MB fp32)
+
+
+# ------------------------------------------------------------------------------------ model / state_dict
+def _stock_vgg16(out_channels=3):
+    """Independent torch.nn re-statement of the reference architecture (model/vgg16.py) used to
+    check checkpoint key / shape compatibility."""
+    def block(cin, cout, n):
+        layers = []
+        for i in range(n):
+            layers += [nn.Conv2d(cin if i == 0 else cout, cout, 3, padding=1), nn.ReLU(True)]
+        layers.append(nn.MaxPool2d(2, 2))
+        m = nn.Module()
+        m.conv = nn.Sequential(*layers)
+        return m
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = nn.Sequential(block(3, 64, 2), block(64, 128, 2), block(128, 256, 3),
+                                          block(256, 512, 3), block(512, 512, 3))
+            self.linear1 = nn.Linear(25088, 4096)
+            self.linear2 = nn.Linear(4096, 4096)
+            self.linear3 = nn.Linear(4096, out_channels)
+
+        def forward(self, x):
+            for b in self.backbone:
+                x = b.conv(x)
+            x = torch.flatten(nn.functional.adaptive_avg_pool2d(x, (7, 7)), 1)
+            x = torch.relu(self.linear1(x))
+            x = torch.relu(self.linear2(x))
+            return self.linear3(x)
+    return Net()
+
+
+def test_vgg16_state_dict_is_reference_compatible():
+    torch.manual_seed(0)
+    m = VGG16(3, 3, True).eval()
+    sd = m.state_dict()
+    stock = _stock_vgg16().eval()
+    ref_keys = list(stock.state_dict().keys())
+    assert list(sd.keys()) == ref_keys and len(ref_keys) == 32
+    assert sum(v.numel() for v in sd.values()) == 134272835
+    for k, v in sd.items():
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.shape == stock.state_dict()[k].shape
+    stock.load_state_dict(sd)                                # our checkpoint loads into stock torch
+    x = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        assert torch.allclose(m(x), stock(x), atol=1e-5)
+    m2 = VGG16(3, 3, False)
+    m2.load_state_dict(stock.state_dict())                   # and the other way round
+    with torch.no_grad():
+        assert torch.allclose(m2.eval()(x), stock(x), atol=1e-5)
+    # init statistics of the reference (model/vgg16.py:49-57)
+    assert abs(sd["linear2.weight"].std().item() - 0.01) < 5e-4
+    assert sd["linear1.bias"].abs().max().item() == 0
+    w = sd["backbone.2.conv.2.weight"]
+    assert abs(w.std().item() - math.sqrt(2.0 / (256 * 9))) < 1e-3
+
+
+def test_arena_views_alias_parameters():
+    m = VGG16(3, 3, True)
+    a = m.param_arena
+    assert a.total >= 134272835 and len(a.params) == 32
+    p = m.backbone[1].conv[0].weight
+    assert p.shape == (128, 64, 3, 3) and p.is_contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        p[5, 7, 1, 2] = 42.0
+    assert a.mem2d(a.flat_master, p).view(128, 3, 3, 64)[5, 1, 2, 7].item() == 42.0
+    assert p.grad is not None and p.grad.data_ptr() == a._logical_view(a.flat_grad, a.index[id(p)]).data_ptr()
+
+
+# ------------------------------------------------------------------------------------ optimizers
+def _tiny_models():
+    torch.manual_seed(0)
+    m1 = VGG16(3, 3, True, dropout=0.0)
+    m2 = _stock_vgg16()
+    m2.load_state_dict(m1.state_dict())
+    return m1, m2
+
+
+def test_fused_sgd_matches_torch_sgd_and_state_dict_schema():
+    m1, m2 = _tiny_models()
+    o1 = FusedSGD(m1, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    o2 = torch.optim.SGD(m2.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    s1 = torch.optim.lr_scheduler.MultiStepLR(o1, [2, 3], gamma=0.1)
+    s2 = torch.optim.lr_scheduler.MultiStepLR(o2, [2, 3], gamma=0.1)
+    x = torch.randn(4, 3, 32, 32)
+    y = torch.randint(0, 3, (4,))
+    for step in range(4):
+        for m, o, s in ((m1, o1, s1), (m2, o2, s2)):
+            o.zero_grad()
+            nn.functional.cross_entropy(m(x), y).backward()
+            o.step()
+            s.step()
+        assert s1.get_last_lr() == s2.get_last_lr()
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.allclose(v1, v2, atol=2e-6, rtol=1e-5), k1
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert set(sd2["param_groups"][0]) <= set(sd1["param_groups"][0])
+    assert set(sd1["state"].keys()) == set(sd2["state"].keys())
+    for i in sd2["state"]:
+        b1, b2 = sd1["state"][i]["momentum_buffer"], sd2["state"][i]["momentum_buffer"]
+        assert b1.shape == b2.shape and b1.is_contiguous() and torch.allclose(b1, b2, atol=2e-6, rtol=1e-5)
+    # a torch.optim.SGD checkpoint resumes the fused optimizer (and vice versa)
+    o3 = FusedSGD(m1, lr=0.05, momentum=0.9, weight_decay=1e-4)
+    o3.load_state_dict(sd2)
+    assert torch.allclose(o3._flat_state["momentum_buffer"], o1._flat_state["momentum_buffer"], atol=2e-6)
+    sd1.pop("fused_steps")
+    o2.load_state_dict(sd1)
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """Same random gradients fed to both (back-propagated gradients differ in the last bit between
+    the two conv layouts, and Adam's g/(|g|+eps) amplifies that for near-zero entries)."""
+    m1, m2 = _tiny_models()
+    o1 = FusedAdamW(m1, lr=1e-3, weight_decay=0.01)
+    o2 = torch.optim.AdamW(m2.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+    for step in range(3):
+        o1.zero_grad()
+        for p1, p2 in zip(m1.parameters(), m2.parameters()):
+            gr = torch.randn(p2.shape, generator=g) * 1e-2
+            p2.grad = gr.clone()
+            p1.grad.copy_(gr)
+        o1.step()
+        o2.step()
+    for (k1, v1), (k2, v2) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.allclose(v1, v2, atol=1e-6, rtol=1e-5), k1
+
+
+# ------------------------------------------------------------------------------------ checkpoint
+def test_snapshot_schema_atomic_write_and_roundtrip(tmp_path):
+    m1, _ = _tiny_models()
+    o1 = FusedSGD(m1, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    s1 = torch.optim.lr_scheduler.MultiStepLR(o1, [50, 100, 200], gamma=0.1)
+    path = str(tmp_path / "weights" / "last.pth")
+    ckpt.save_snapshot(path, 7, m1, o1, s1, extra=dict(best_fitness=dict(epoch=3, value=0.5, metrics={"accuracy": 0.5})))
+    assert os.listdir(os.path.dirname(path)) == ["last.pth"]        # no temp files left behind
+    snap = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(["epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"]) <= set(snap)
+    assert snap["epoch"] == 7 and snap["best_fitness"]["epoch"] == 3
+    assert snap["scheduler_state_dict"]["gamma"] == 0.1
+    stock = _stock_vgg16()
+    stock.load_state_dict(snap["model_state_dict"])                  # reference-style consumer (eval.py:48-49)
+    snap2 = ckpt.load_snapshot(path)
+    assert snap2["epoch"] == 7
+    bad = str(tmp_path / "bad.pth")
+    torch.save(dict(epoch=1), bad)
+    with pytest.raises(KeyError):
+        ckpt.load_snapshot(bad)
+
+
+# ------------------------------------------------------------------------------------ reducer (single process)
+def test_reducer_world1_grads_are_bucket_views_and_survive_set_to_none():
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4))
+    red = BucketedReducer(list(net.parameters()), bucket_cap_mb=0.0001, first_bucket_mb=0.0001)
+    assert len(red.buckets) >= 2
+    x = torch.randn(5, 8)
+    net(x).sum().backward()
+    ref = [p.grad.clone() for p in net.parameters()]
+    for p in net.parameters():
+        v = red._whole_param_view(p)
+        assert v is not None and p.grad.data_ptr() == v.data_ptr()
+    for p in net.parameters():
+        p.grad = None                                               # optimizer.zero_grad(set_to_none=True)
+    net(x).sum().backward()
+    for p, r in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, r)
+        assert p.grad.data_ptr() == red._whole_param_view(p).data_ptr()
+    assert red.stats["finalized"] == 2
+    with red.no_sync():
+        net(x).sum().backward()                                     # accumulates locally
+    for p, r in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, 2 * r)
