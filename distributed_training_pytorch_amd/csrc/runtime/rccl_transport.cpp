@@ -1,0 +1,165 @@
+// Native gradient-bucket transport: a dedicated RCCL communicator + HIP communication stream per
+// process, event-synchronised with the compute stream.
+//
+//   producer (backward kernels, compute stream) --event--> comm stream: ncclAllReduce(bucket)
+//   comm stream --event--> consumer (optimizer, compute stream)
+//
+// The bucket all-reduces run on their own stream, so they overlap with the remaining backward
+// kernels; nothing here blocks the host.  Averaging is folded into the collective (ncclAvg).
+// One process per GPU; the unique id is created on rank 0 and distributed by the caller (through
+// the torch.distributed store), so this file has no dependency on PyTorch.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct Transport {
+  ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  int rank = 0, world = 1, device = 0;
+  std::vector<hipEvent_t> events;   // ring of reusable events
+  size_t next_event = 0;
+  unsigned long long launched = 0, bytes = 0;
+  std::mutex mu;
+
+  hipEvent_t event() {
+    if (events.size() < 64) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      events.push_back(e);
+      return e;
+    }
+    hipEvent_t e = events[next_event % events.size()];
+    ++next_event;
+    return e;
+  }
+};
+
+inline int fail(const char* what, int code) {
+  std::fprintf(stderr, "[dtp_runtime] %s failed (%d)\n", what, code);
+  return code ? code : -1;
+}
+
+#define DTP_HIP(x)                                   \
+  do {                                               \
+    hipError_t e_ = (x);                             \
+    if (e_ != hipSuccess) return fail(#x, (int)e_);  \
+  } while (0)
+#define DTP_NCCL(x)                                      \
+  do {                                                   \
+    ncclResult_t r_ = (x);                               \
+    if (r_ != ncclSuccess) return fail(#x, 1000 + (int)r_); \
+  } while (0)
+
+ncclDataType_t dtype_of(int kind) { return kind == 1 ? ncclBfloat16 : ncclFloat32; }
+
+}  // namespace
+
+extern "C" {
+
+int dtp_rccl_unique_id(void* out, int out_bytes) {
+  if (out_bytes < (int)sizeof(ncclUniqueId)) return -2;
+  ncclUniqueId id;
+  DTP_NCCL(ncclGetUniqueId(&id));
+  std::memcpy(out, &id, sizeof(id));
+  return (int)sizeof(id);
+}
+
+int dtp_rccl_unique_id_bytes() { return (int)sizeof(ncclUniqueId); }
+
+void* dtp_rccl_create(const void* id_bytes, int rank, int world, int device) {
+  if (world < 1 || rank < 0 || rank >= world) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  auto* t = new Transport();
+  t->rank = rank; t->world = world; t->device = device;
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof(id));
+  if (ncclCommInitRank(&t->comm, world, id, rank) != ncclSuccess) { delete t; return nullptr; }
+  // high priority: small collectives should not queue behind long compute kernels' tails
+  int lo = 0, hi = 0;
+  hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+    ncclCommDestroy(t->comm);
+    delete t;
+    return nullptr;
+  }
+  return t;
+}
+
+// In-place all-reduce of buf[count] once everything already queued on producer_stream is done.
+int dtp_rccl_allreduce_async(void* h, void* buf, size_t count, int dtype_kind, int average,
+                             hipStream_t producer_stream) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t || !buf || count == 0) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  hipEvent_t ready = t->event();
+  if (!ready) return -3;
+  DTP_HIP(hipEventRecord(ready, producer_stream));
+  DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
+  DTP_NCCL(ncclAllReduce(buf, buf, count, dtype_of(dtype_kind), average ? ncclAvg : ncclSum, t->comm,
+                         t->comm_stream));
+  t->launched += 1;
+  t->bytes += count * (dtype_kind == 1 ? 2 : 4);
+  return 0;
+}
+
+// Make consumer_stream wait for every collective launched so far (no host blocking).
+int dtp_rccl_wait(void* h, hipStream_t consumer_stream) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  hipEvent_t done = t->event();
+  if (!done) return -3;
+  DTP_HIP(hipEventRecord(done, t->comm_stream));
+  DTP_HIP(hipStreamWaitEvent(consumer_stream, done, 0));
+  return 0;
+}
+
+int dtp_rccl_broadcast(void* h, void* buf, size_t count, int dtype_kind, int root, hipStream_t stream) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t || !buf) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  hipEvent_t ready = t->event();
+  if (!ready) return -3;
+  DTP_HIP(hipEventRecord(ready, stream));
+  DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
+  DTP_NCCL(ncclBroadcast(buf, buf, count, dtype_of(dtype_kind), root, t->comm, t->comm_stream));
+  hipEvent_t done = t->event();
+  if (!done) return -3;
+  DTP_HIP(hipEventRecord(done, t->comm_stream));
+  DTP_HIP(hipStreamWaitEvent(stream, done, 0));
+  return 0;
+}
+
+int dtp_rccl_sync(void* h) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t) return -2;
+  DTP_HIP(hipStreamSynchronize(t->comm_stream));
+  return 0;
+}
+
+int dtp_rccl_stats(void* h, unsigned long long* launched, unsigned long long* bytes) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t) return -2;
+  *launched = t->launched;
+  *bytes = t->bytes;
+  return 0;
+}
+
+int dtp_rccl_destroy(void* h) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t) return 0;
+  hipStreamSynchronize(t->comm_stream);
+  for (hipEvent_t e : t->events) hipEventDestroy(e);
+  ncclCommDestroy(t->comm);
+  hipStreamDestroy(t->comm_stream);
+  delete t;
+  return 0;
+}
+
+}  // extern "C"

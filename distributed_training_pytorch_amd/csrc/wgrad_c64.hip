@@ -1,0 +1,238 @@
+// Weight gradient of 3x3 convolutions with 64 input channels (VGG conv1_2: 64->64 @224^2,
+// conv2_1: 64->128 @112^2) for gfx950.
+//
+// The generic TT kernel (wgrad.hip) gives one (tap, channel-block) output tile to a workgroup, so a
+// 64x64 tile re-reads 16 KB of activations per 32 MFMAs and all nine taps re-read the same input:
+// at 64 channels it is bound by the LDS fill rate of a CU (measured 207 TF/s).  This kernel keeps
+// ALL NINE TAPS of a [COUT x 9*64] gradient in one workgroup's accumulators and walks down an image
+// column strip of 32 pixels: per step it loads ONE new input row segment (34 px incl. halo) into a
+// 4-slot LDS ring — rows h-1, h, h+1 are already resident — plus the dY row segment, and issues
+// 36 MFMAs per wave (4 output-channel blocks x 9 taps).  Each activation byte is fetched from
+// global memory ~1.06x instead of 9x.
+//   * operands are staged row-major by LDS-DMA and read transposed (ds_read_b64_tr_b16), with the
+//     conflict-free XOR swizzle of wgrad.hip applied on the global source address;
+//   * image borders / strip tails are redirected per lane to a zeroed page;
+//   * a persistent grid accumulates over many (image, strip, row-chunk) work items; per-workgroup
+//     f32 partials are summed by a deterministic reduce kernel (beta / dtype cast fused).
+#include "dtp_common.h"
+
+struct WgC64Params {
+  const char* dY;        // [N*H*W][COUT] bf16
+  const char* X;         // [N*H*W][64]   bf16
+  float* partial;        // [gridDim.x][COUT][576] f32
+  const char* zero_page;
+  int N, H, W;
+  int S;                 // 32-pixel strips per image row
+  int RC;                // row chunks per strip
+  int rows_per_chunk;
+  int nchunks;
+};
+
+DTP_DEVINL int sw128(int row) { return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1; }
+DTP_DEVINL int sw256(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 1; }
+
+template <int COUT>
+__global__ __launch_bounds__(COUT * 4) void wgrad_c64_kernel(const WgC64Params p) {
+  constexpr int T = COUT * 4;
+  constexpr int NW = T / 64;              // 4 or 8 waves
+  constexpr int RBA = COUT * 2;           // dY LDS row bytes (128 / 256)
+  constexpr int DY_BYTES = 32 * RBA;
+  constexpr int DY_WI = DY_BYTES / 1024;  // 1-KiB LDS-DMA pieces per dY tile (4 / 8)
+  constexpr int X_SLOT = 40 * 128;        // 34 px + 6 pad rows
+  constexpr int X_WI = 5;
+  typedef __attribute__((ext_vector_type(4))) short s4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lX = smem;                        // 4 ring slots
+  char* lD = smem + 4 * X_SLOT;           // 2 dY buffers
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- per-lane staging geometry
+  // X piece wi (0..4): row pos = wi*8 + (lane>>3), physical chunk lane&7
+  const int xr = lane >> 3, xpc = lane & 7;
+  // dY piece di: COUT=64: 8 rows of 8 chunks; COUT=128: 4 rows of 16 chunks
+  constexpr int D_LPR = RBA / 16;         // lanes per dY row (8 / 16)
+  const int dr = lane / D_LPR, dpc = lane % D_LPR;
+
+  // ---- per-lane fragment geometry
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int krow = 8 * g4 + q;
+  const int sub = pp >> 1, half8 = (pp & 1) * 8;
+  const int sa = (RBA >= 256) ? sw256(krow) : sw128(krow);
+  const int a_cw = (wm * 64) >> 3;
+  // X fragment byte offsets inside a ring slot for dx = -1, 0, +1 and the two 4-row reads
+  int xo[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int pos = krow + d + 4 * r;   // = krow + dx + 1 (+4)
+      xo[d][r] = pos * 128 + ((((2 * wn) ^ sw128(pos)) + sub) << 4) + half8;
+    }
+
+  f32x4_t acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  for (int chunk = blockIdx.x; chunk < p.nchunks; chunk += gridDim.x) {
+    const int unit = chunk / p.RC, rc = chunk - unit * p.RC;
+    const int n = unit / p.S, s = unit - n * p.S;
+    const int w0 = s * 32;
+    const int h0 = rc * p.rows_per_chunk;
+    int h1 = h0 + p.rows_per_chunk;
+    if (h1 > p.H) h1 = p.H;
+    const size_t img_px = (size_t)n * p.H * p.W;
+
+    auto stage_x = [&](int hrow) {       // input row segment [w0-1, w0+33) of row hrow -> ring slot
+      char* slot = lX + ((hrow + 1) & 3) * X_SLOT;
+      const bool row_ok = hrow >= 0 && hrow < p.H;
+#pragma unroll
+      for (int k = 0; k < (X_WI + NW - 1) / NW; ++k) {
+        const int wi = wave + k * NW;
+        if (wi < X_WI) {
+          const int pos = wi * 8 + xr;
+          const int w = w0 - 1 + pos;
+          const bool ok = row_ok && pos < 34 && w >= 0 && w < p.W;
+          const int lc = xpc ^ sw128(pos);
+          const char* g = ok ? p.X + ((img_px + (size_t)hrow * p.W + w) * 64 + lc * 8) * 2 : p.zero_page;
+          glds16(g, slot + wi * 1024);
+        }
+      }
+    };
+    auto stage_dy = [&](int hrow) {      // dY row segment [w0, w0+32) of row hrow -> buffer hrow&1
+      char* buf = lD + (hrow & 1) * DY_BYTES;
+#pragma unroll
+      for (int k = 0; k < (DY_WI + NW - 1) / NW; ++k) {
+        const int di = wave + k * NW;
+        if (di < DY_WI) {
+          const int px = di * (64 / D_LPR) + dr;
+          const int lc = dpc ^ ((RBA >= 256) ? sw256(px) : sw128(px));
+          const bool ok = (w0 + px) < p.W;
+          const char* g = ok ? p.dY + ((img_px + (size_t)hrow * p.W + w0 + px) * COUT + lc * 8) * 2 : p.zero_page;
+          glds16(g, buf + di * 1024);
+        }
+      }
+    };
+
+    __syncthreads();                     // previous chunk completely consumed
+    stage_x(h0 - 1);
+    stage_x(h0);
+    stage_x(h0 + 1);
+    stage_dy(h0);
+    for (int h = h0; h < h1; ++h) {
+      __syncthreads();                   // loads for step h landed (vmcnt(0) + barrier); step h-1 consumed
+      if (h + 1 < h1) {
+        stage_x(h + 2);
+        stage_dy(h + 1);
+      }
+      const char* bD = lD + (h & 1) * DY_BYTES;
+      bf16x8_t af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = ((a_cw + 2 * i) ^ sa) + sub;
+        const char* a0 = bD + krow * RBA + (ch << 4) + half8;
+        s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
+        s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 4 * RBA));
+        af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const char* slot = lX + ((h + dyi) & 3) * X_SLOT;     // row h + dyi - 1 lives in slot (row+1)&3
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+          s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slot + xo[dxi][0]));
+          s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slot + xo[dxi][1]));
+          const bf16x8_t bf = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[i][dyi * 3 + dxi] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][dyi * 3 + dxi], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- partial slab: lane owns dW[cout = .. + li][tap*64 + wn*16 + g4*4 .. +3]
+  float* slab = p.partial + (size_t)blockIdx.x * COUT * 576;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = wm * 64 + i * 16 + li;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *(f32x4_t*)(slab + (size_t)m * 576 + t * 64 + wn * 16 + g4 * 4) = acc[i][t];
+  }
+}
+
+// out = beta*out + sum_g partial[g]   (total % 4 == 0)
+__global__ void wgrad_c64_reduce_kernel(const float* __restrict__ partial, int G, size_t total,
+                                        void* __restrict__ out, int out_fp32, float beta) {
+  const size_t nvec = total >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (size_t)gridDim.x * blockDim.x) {
+    f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    int g = 0;
+    for (; g + 3 < G; g += 4) {
+      v0 += *(const f32x4_t*)(partial + (size_t)g * total + (i << 2));
+      v1 += *(const f32x4_t*)(partial + (size_t)(g + 1) * total + (i << 2));
+      v2 += *(const f32x4_t*)(partial + (size_t)(g + 2) * total + (i << 2));
+      v3 += *(const f32x4_t*)(partial + (size_t)(g + 3) * total + (i << 2));
+    }
+    for (; g < G; ++g) v0 += *(const f32x4_t*)(partial + (size_t)g * total + (i << 2));
+    f32x4_t v = (v0 + v1) + (v2 + v3);
+    if (out_fp32) {
+      float* d = (float*)out + (i << 2);
+      if (beta != 0.f) v += *(const f32x4_t*)d * beta;
+      *(f32x4_t*)d = v;
+    } else {
+      bf16_t* d = (bf16_t*)out + (i << 2);
+      if (beta != 0.f) {
+        const u32x2_t old = *(const u32x2_t*)d;
+        v[0] += beta * bf16_to_f32((bf16_t)(old[0] & 0xFFFFu));
+        v[1] += beta * bf16_to_f32((bf16_t)(old[0] >> 16));
+        v[2] += beta * bf16_to_f32((bf16_t)(old[1] & 0xFFFFu));
+        v[3] += beta * bf16_to_f32((bf16_t)(old[1] >> 16));
+      }
+      u32x2_t pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *(u32x2_t*)d = pk;
+    }
+  }
+}
+
+// dY [N,H,W,Cout] bf16, X [N,H,W,64] bf16 -> out [Cout][9*64].  partial: >= max_grid*Cout*576 floats.
+extern "C" int dtp_wgrad_c64(const void* dY, const void* X, void* out, float* partial, int max_grid,
+                             const void* zero_page, int N, int H, int W, int Cout, int out_fp32, float beta,
+                             hipStream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || (Cout != 64 && Cout != 128) || max_grid < 1) return -10;
+  WgC64Params p;
+  p.dY = (const char*)dY; p.X = (const char*)X; p.partial = partial; p.zero_page = (const char*)zero_page;
+  p.N = N; p.H = H; p.W = W;
+  p.S = (W + 31) / 32;
+  const int units = N * p.S;
+  // enough row chunks for ~4 work items per workgroup, at least ~16 rows each
+  int rc = (4 * max_grid + units - 1) / units;
+  if (rc > H / 16) rc = H / 16;
+  if (rc < 1) rc = 1;
+  p.rows_per_chunk = (H + rc - 1) / rc;
+  p.RC = (H + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  p.nchunks = units * p.RC;
+  const int grid = p.nchunks < max_grid ? p.nchunks : max_grid;
+  if (Cout == 64) {
+    constexpr int lds = 4 * 40 * 128 + 2 * 32 * 128;
+    hipLaunchKernelGGL(wgrad_c64_kernel<64>, dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    constexpr int lds = 4 * 40 * 128 + 2 * 32 * 256;
+    hipLaunchKernelGGL(wgrad_c64_kernel<128>, dim3(grid), dim3(512), lds, stream, p);
+  }
+  if (DTP_CHECK_LAUNCH() != 0) return -1;
+  const size_t total = (size_t)Cout * 576;
+  int blocks = (int)((total / 4 + 255) / 256);
+  hipLaunchKernelGGL(wgrad_c64_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, grid, total, out,
+                     out_fp32, beta);
+  return DTP_CHECK_LAUNCH();
+}

@@ -88,8 +88,19 @@ def pick_wgrad(M, C, taps, ksteps):
             cfg = 3 if C >= 128 else 4
     bm, bn = WGRAD_TILES[cfg]
     tiles = _cdiv(M, bm) * (taps * (C // bn) if taps == 9 else _cdiv(C, bn))
-    nsplit = max(1, min(ksteps // 8 if ksteps >= 16 else 1, _cdiv(4 * N_CU, tiles)))
-    return cfg, nsplit
+    # split the reduction so that tiles*nsplit fills whole rounds of the 256 CUs (big tiles run one
+    # workgroup per CU); fewer, fuller rounds also mean fewer f32 partial slabs to write and re-read
+    per_cu = 1 if bm * bn >= 256 * 256 else 2
+    slots = N_CU * per_cu
+    max_split = max(1, ksteps // 8) if ksteps >= 16 else 1
+    nsplit = 1
+    for rounds in (1, 2, 3, 4):
+        n = (slots * rounds) // tiles
+        if n >= 1:
+            nsplit = min(n, max_split)
+            if n <= max_split and tiles * n >= 0.85 * slots * rounds:
+                break
+    return cfg, max(1, nsplit)
 
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
@@ -204,6 +215,15 @@ def conv3x3_wgrad(dy, x, out, beta=0.0):
         raise ValueError("conv3x3_wgrad: bad shapes dy=%s x=%s" % (tuple(dy.shape), tuple(x.shape)))
     if out.numel() != Co * 9 * C or not out.is_contiguous() or out.dtype not in (torch.float32, BF16):
         raise ValueError("conv3x3_wgrad: bad out")
+    if C == 64 and Co in (64, 128) and "wgrad" not in _overrides:
+        # all-nine-taps column-strip kernel: activations are fetched ~once instead of 9x
+        max_grid = 2 * N_CU if Co == 64 else N_CU
+        partial = workspace.get("wgrad_partial", max_grid * Co * 576, torch.float32, dy.device)
+        rc = _lib.hip().dtp_wgrad_c64(ptr(dy), ptr(x), ptr(out), ptr(partial), max_grid,
+                                      ptr(workspace.zero_page(dy.device)), N, H, W, Co,
+                                      int(out.dtype == torch.float32), float(beta), stream())
+        check(rc, "wgrad_c64")
+        return out
     return _wgrad(dy, x, out, N * H * W, Co, 9 * C, C, 9, H, W, Co, C, beta)
 
 

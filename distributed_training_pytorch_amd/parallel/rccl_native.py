@@ -1,0 +1,110 @@
+"""Python face of the native RCCL bucket transport (``csrc/runtime/rccl_transport.cpp``).
+
+The reducer hands each ready bucket to :meth:`launch`; the C++ side records an event on the
+compute stream, makes its own high-priority communication stream wait for it and issues
+``ncclAllReduce(..., ncclAvg)`` there, so communication overlaps with the rest of backward on
+separate HIP streams.  :meth:`wait` makes the compute stream wait (device-side, no host sync) for
+all collectives before the optimizer runs.  The RCCL unique id is created on rank 0 and shared
+through the already-initialised ``torch.distributed`` process group (any backend), which stays
+in charge of barriers / object broadcasts.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from . import comm
+
+_KIND = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _rt():
+    rt = _lib.runtime()
+    if not getattr(rt, "_dtp_typed", False):
+        vp, ci, st = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+        rt.dtp_rccl_unique_id.argtypes = [vp, ci]
+        rt.dtp_rccl_unique_id.restype = ci
+        rt.dtp_rccl_unique_id_bytes.restype = ci
+        rt.dtp_rccl_create.argtypes = [vp, ci, ci, ci]
+        rt.dtp_rccl_create.restype = vp
+        rt.dtp_rccl_allreduce_async.argtypes = [vp, vp, st, ci, ci, vp]
+        rt.dtp_rccl_allreduce_async.restype = ci
+        rt.dtp_rccl_wait.argtypes = [vp, vp]
+        rt.dtp_rccl_wait.restype = ci
+        rt.dtp_rccl_broadcast.argtypes = [vp, vp, st, ci, ci, vp]
+        rt.dtp_rccl_broadcast.restype = ci
+        rt.dtp_rccl_sync.argtypes = [vp]
+        rt.dtp_rccl_sync.restype = ci
+        rt.dtp_rccl_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+        rt.dtp_rccl_stats.restype = ci
+        rt.dtp_rccl_destroy.argtypes = [vp]
+        rt.dtp_rccl_destroy.restype = ci
+        rt._dtp_typed = True
+    return rt
+
+
+class NativeRcclTransport(object):
+    def __init__(self, rank=None, world=None, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeRcclTransport needs a GPU")
+        self.rt = _rt()
+        self.rank = comm.rank() if rank is None else rank
+        self.world = comm.world_size() if world is None else world
+        self.device = torch.cuda.current_device() if device is None else device
+        n = self.rt.dtp_rccl_unique_id_bytes()
+        buf = ctypes.create_string_buffer(n)
+        if self.rank == 0:
+            if self.rt.dtp_rccl_unique_id(buf, n) != n:
+                raise RuntimeError("ncclGetUniqueId failed")
+        payload = bytes(buf.raw)
+        if self.world > 1:
+            payload = comm.broadcast_object(payload, src=0)
+        idbuf = ctypes.create_string_buffer(payload, n)
+        self.handle = self.rt.dtp_rccl_create(idbuf, self.rank, self.world, self.device)
+        if not self.handle:
+            raise RuntimeError("ncclCommInitRank failed (rank %d of %d)" % (self.rank, self.world))
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def launch(self, flat):
+        if flat.dtype not in _KIND or not flat.is_cuda or not flat.is_contiguous():
+            raise ValueError("RCCL transport reduces contiguous CUDA f32/bf16 buffers")
+        rc = self.rt.dtp_rccl_allreduce_async(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                              _KIND[flat.dtype], 1, self._stream())
+        if rc != 0:
+            raise RuntimeError("dtp_rccl_allreduce_async failed: %d" % rc)
+        return True
+
+    def wait(self, handle, flat):
+        if handle is None:
+            return
+        rc = self.rt.dtp_rccl_wait(self.handle, self._stream())
+        if rc != 0:
+            raise RuntimeError("dtp_rccl_wait failed: %d" % rc)
+
+    def broadcast(self, flat, src=0):
+        if self.world == 1:
+            return
+        rc = self.rt.dtp_rccl_broadcast(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                        _KIND[flat.dtype], src, self._stream())
+        if rc != 0:
+            raise RuntimeError("dtp_rccl_broadcast failed: %d" % rc)
+
+    def stats(self):
+        a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        self.rt.dtp_rccl_stats(self.handle, ctypes.byref(a), ctypes.byref(b))
+        return dict(launched=a.value, bytes=b.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.rt.dtp_rccl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
