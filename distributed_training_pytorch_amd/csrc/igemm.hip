@@ -241,10 +241,160 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     }
   };
 
+  // ======================= PIPE == 2: 8-phase schedule, LDS-DMA in flight across barriers ===========
+  // (cdna_hip_programming.md "256^2 8-phase template", re-derived for the implicit GEMM.)
+  // LDS = 8 half-tile slots of 16 KiB: [dbuf][A0, A1, B0, B1]; a half-tile holds, for every wave,
+  // one half of its rows (A: 64 of its 128 pixels, B: 32 of its 64 channels) x 64 k.
+  // A K-tile is consumed in four quadrant phases (A0B0, A0B1, A1B1, A1B0); each phase issues ONE
+  // half-tile of LDS-DMA (2 global_load_lds per lane) for a tile 1.5-2 K-tiles ahead, waits with a
+  // COUNTED vmcnt(8) (4 half-tiles stay in flight across the barriers; never vmcnt(0) in the loop),
+  // and runs 16 MFMAs between two raw s_barriers.  The two wave rows (wm = 0/1) are staggered by
+  // one barrier, so one group's ds_reads/address work overlaps the other group's MFMAs.
+  // Hazard bookkeeping (derivation in docs/KERNELS.md):
+  //   RAW  every slot is read >= 1 phase after the vmcnt that retires its DMA (+ a barrier);
+  //   WAR  every slot is re-staged >= 2 phases after its last ds_read (covers the stagger).
+  if constexpr (PIPE == 2) {
+    static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4 || PIPE != 2, "8-phase needs the 256x256 2x4 tile");
+    constexpr int SLOT = 16384;
+    // B half-tile staging pointers: LDS row rho = 64*j + srow  <->  tile row ((rho>>5)<<6) + h*32 + (rho&31)
+    const char* bp8[2][2];
+    bool bk8[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rho = 64 * j + srow;
+        const int n = n0 + ((rho >> 5) << 6) + h * 32 + (rho & 31);
+        bk8[h][j] = n < p.Ncols;
+        bp8[h][j] = p.B + ((size_t)n * p.ldb + lch * 8) * 2;
+      }
+    auto koffs = [&](int T, int& tap, long& koffA, long& koffB) {
+      int cc = T;
+      tap = 0;
+      if (TAPS9) {
+        tap = T / cchunks;
+        cc = T - tap * cchunks;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        koffA = ((long)(dy * p.W + dx) * p.C + cc * 64) * 2;
+        koffB = ((long)tap * p.C + cc * 64) * 2;
+      } else {
+        koffA = (long)cc * 128;
+        koffB = (long)cc * 128;
+      }
+    };
+    auto issue_A = [&](auto h_, auto d_, int T) {   // half-tile A_h of K-tile T -> slot [d][h]
+      constexpr int h = decltype(h_)::value, d = decltype(d_)::value;
+      int tap; long ka, kb;
+      koffs(T, tap, ka, kb);
+      const bool live = T < kend;
+      char* dst = smem + (d * 4 + h) * SLOT + wave * 1024;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = live && ((amask[2 * j + h] >> tap) & 1u);
+        const char* g = ok ? aptr[2 * j + h] + ka : p.zero_page;
+        glds16(g, dst + j * 8192);
+      }
+    };
+    auto issue_B = [&](auto h_, auto d_, int T) {
+      constexpr int h = decltype(h_)::value, d = decltype(d_)::value;
+      int tap; long ka, kb;
+      koffs(T, tap, ka, kb);
+      const bool live = T < kend;
+      char* dst = smem + (d * 4 + 2 + h) * SLOT + wave * 1024;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const char* g = (live && bk8[h][j]) ? bp8[h][j] + kb : p.zero_page;
+        glds16(g, dst + j * 8192);
+      }
+    };
+    // fragment registers are plain named arrays used through macros (passing them to lambdas by
+    // reference sent them to scratch)
+    bf16x8_t xa[2][4], b0f[2][2], b1f[2][2];
+#define DTP_READ_A(h, d)                                                                              \
+  {                                                                                                   \
+    const char* s_ = smem + ((d) * 4 + (h)) * SLOT + (wm * 64) * 128;                                 \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)    \
+        xa[ks][i] = *(const bf16x8_t*)(s_ + i * 2048 + (ks ? foff1 : foff0));                         \
+  }
+#define DTP_READ_B(h, d, dst)                                                                         \
+  {                                                                                                   \
+    const char* s_ = smem + ((d) * 4 + 2 + (h)) * SLOT + (wn * 32) * 128;                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+        dst[ks][j] = *(const bf16x8_t*)(s_ + j * 2048 + (ks ? foff1 : foff0));                        \
+  }
+#define DTP_MMA(mh, nh, bf)                                                                           \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(mh) * 4 + i][(nh) * 2 + j] =                 \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], xa[ks][i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+#define DTP_PHASE_SYNC_IN()                                   \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+  __builtin_amdgcn_s_barrier();                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+  __builtin_amdgcn_sched_barrier(0);                          \
+  __builtin_amdgcn_s_setprio(1);
+#define DTP_PHASE_SYNC_OUT()                                  \
+  __builtin_amdgcn_s_setprio(0);                              \
+  __builtin_amdgcn_sched_barrier(0);                          \
+  __builtin_amdgcn_s_barrier();                               \
+  __builtin_amdgcn_sched_barrier(0);
+
+    // prologue: tile kbeg entirely, tile kbeg+1's B0/A0 (issue order = consumption order)
+    issue_B(I0{}, I0{}, kbeg);
+    issue_A(I0{}, I0{}, kbeg);
+    issue_B(I1{}, I0{}, kbeg);
+    issue_A(I1{}, I0{}, kbeg);
+    issue_B(I0{}, I1{}, kbeg + 1);
+    issue_A(I0{}, I1{}, kbeg + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
+    __builtin_amdgcn_sched_barrier(0);
+
+    int t = kbeg;
+    for (; t < kend; t += 2) {
+      // ---- K-tile t (dbuf 0)
+      DTP_READ_A(0, 0) DTP_READ_B(0, 0, b0f)           // P1
+      issue_B(I1{}, I1{}, t + 1);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(0, 0, b0f) DTP_PHASE_SYNC_OUT();
+      DTP_READ_B(1, 0, b1f)                                // P2
+      issue_A(I1{}, I1{}, t + 1);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(0, 1, b1f) DTP_PHASE_SYNC_OUT();
+      DTP_READ_A(1, 0)                                     // P3
+      issue_B(I0{}, I0{}, t + 2);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(1, 1, b1f) DTP_PHASE_SYNC_OUT();
+      issue_A(I0{}, I0{}, t + 2);                             // P4
+      DTP_PHASE_SYNC_IN(); DTP_MMA(1, 0, b0f) DTP_PHASE_SYNC_OUT();
+      // ---- K-tile t+1 (dbuf 1).  With an odd tile count this is an all-zero tile (loads past kend
+      // come from the zero page): a mid-loop exit here makes hipcc spill the accumulators.
+      DTP_READ_A(0, 1) DTP_READ_B(0, 1, b0f)           // P5
+      issue_B(I1{}, I0{}, t + 2);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(0, 0, b0f) DTP_PHASE_SYNC_OUT();
+      DTP_READ_B(1, 1, b1f)                                // P6
+      issue_A(I1{}, I0{}, t + 2);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(0, 1, b1f) DTP_PHASE_SYNC_OUT();
+      DTP_READ_A(1, 1)                                     // P7
+      issue_B(I0{}, I1{}, t + 3);
+      DTP_PHASE_SYNC_IN(); DTP_MMA(1, 1, b1f) DTP_PHASE_SYNC_OUT();
+      issue_A(I0{}, I1{}, t + 3);                             // P8
+      DTP_PHASE_SYNC_IN(); DTP_MMA(1, 0, b0f) DTP_PHASE_SYNC_OUT();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();     // pair the stagger barrier of the other wave row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain (dummy) DMA before the C image reuses LDS
+#undef DTP_PHASE_SYNC_IN
+#undef DTP_READ_A
+#undef DTP_READ_B
+#undef DTP_MMA
+#undef DTP_PHASE_SYNC_OUT
+  }
+
   // ---------------- main loop: 2 LDS stages, one barrier per K-step
-  if (kbeg < kend) stage(kbeg, 0);
+  if (PIPE != 2 && kbeg < kend) stage(kbeg, 0);
   int buf = 0;
-  if (PIPE == 0) {
+  if (PIPE == 2) {
+    // handled above
+  } else if (PIPE == 0) {
     for (int kt = kbeg; kt < kend; ++kt) {
       __syncthreads();   // stage kt landed everywhere; everyone is done reading the other buffer
       if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
@@ -436,6 +586,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 10: rc = DTP_IG(256, 64, 4, 1, 1); break;
     case 11: rc = DTP_IG(128, 128, 2, 2, 1); break;
     case 12: rc = DTP_IG(128, 64, 2, 1, 1); break;
+    case 16: rc = DTP_IG(256, 256, 2, 4, 2); break;   // 8-phase, counted vmcnt
     default: return -16;
   }
 #undef DTP_IG

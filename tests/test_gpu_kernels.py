@@ -65,7 +65,7 @@ def test_conv3x3_fprop(shape):
     _close(y2, _ref_conv(x, w, None, False), 2e-2, 2e-2, "fprop-nobias%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 16])
 def test_conv3x3_fprop_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(1)
@@ -379,3 +379,25 @@ def test_conv1_fprop_wgrad(shape, in_dtype):
         k.conv1_wgrad(x, dy, gw, gb, beta_w=1.0, beta_b=1.0, **kw)
         _close(gw, 2 * gref, 3e-2, 3e-2 * gref.abs().max().item(), "conv1 wgrad acc")
         _close(gb, 2 * bref, 3e-2, 3e-2 * bref.abs().max().item(), "conv1 bgrad acc")
+
+
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (3, 9, 11, 64, 256), (2, 56, 56, 256, 256)])
+def test_conv3x3_8phase_schedule(shape):
+    """cfg 16: 8-phase loop with LDS-DMA in flight across barriers — even and odd K-tile counts,
+    M/N tails, split-K, dgrad mask epilogue; repeated to screen for DMA/read races."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(21)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    ref = _ref_conv(x, w, b, True)
+    for nsplit in (1, 2, 3):
+        k._overrides["igemm"] = lambda M, Nc, ks: (16, nsplit)
+        try:
+            outs = [k.conv3x3_fprop(x, w, b, relu=True) for _ in range(4)]
+        finally:
+            k._overrides.pop("igemm")
+        _close(outs[0], ref, 2e-2, 2e-2, "8phase%s split%d" % (shape, nsplit))
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
