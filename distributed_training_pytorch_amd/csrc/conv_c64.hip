@@ -1,0 +1,201 @@
+// 3x3 convolution with 64 REDUCTION channels (VGG conv1_2 forward and data-gradient, conv2_1
+// forward) for gfx950: weights live in REGISTERS, activations in a 4-row LDS ring.
+//
+// The generic implicit GEMM (igemm.hip) re-stages a 256-pixel activation tile for each of the nine
+// taps; with only 64 output channels per tile that is 40 KB of LDS fill per 2 MFLOP and the kernel
+// sits on the per-CU LDS-DMA rate (measured ~420-600 TF/s).  Here:
+//   * each wave owns 32 output channels and keeps its whole filter slice, 9 taps x 64 channels =
+//     36 A-fragments of v_mfma_f32_32x32x16_bf16 (144 VGPRs), in registers for the kernel's life;
+//   * a workgroup walks DOWN a 32-pixel-wide image strip: per step ONE new input row segment
+//     (34 px with halo, 4.3 KB) enters a 4-slot LDS ring by LDS-DMA while rows h-1, h, h+1 are
+//     resident; 36 ds_read_b128 + 36 MFMAs produce a 32 px x 32 ch output block per wave;
+//   * global->LDS traffic drops ~9x (each activation row is staged once, not once per tap), so the
+//     loop is MFMA-paced instead of fill-paced;
+//   * bias initialises the accumulator; ReLU (forward) or the ReLU-backward mask of the consumer
+//     (data-gradient) is applied on the way out; stores are 64-byte row segments via a per-wave
+//     LDS shuffle.
+// Borders / strip tails are redirected per lane to a zeroed page.  XOR swizzle (chunk ^= (pos>>1)&7)
+// on the DMA source address and on the reads keeps the 32-row fragment reads conflict-free.
+#include "dtp_common.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+struct ConvC64Params {
+  const char* X;         // [N*H*W][64] bf16
+  const char* Wt;        // [O][9*64] bf16
+  const float* bias;     // [O] or null
+  const char* mask_src;  // [N*H*W][O] bf16 or null
+  char* out;             // [N*H*W][O] bf16
+  const char* zero_page;
+  int N, H, W;
+  int S, RC, rows_per_chunk;
+  int relu;
+  float mask_scale;
+};
+
+template <int O>
+__global__ __launch_bounds__(O * 2) void conv_c64_kernel(const ConvC64Params p) {
+  constexpr int NW = O / 32;             // waves per workgroup (2 or 4)
+  constexpr int X_SLOT = 40 * 128;
+  constexpr int X_WI = 5;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lX = smem;                       // 4 ring slots
+  char* lO = smem + 4 * X_SLOT;          // per-wave 2 KiB output shuffle
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hb = lane >> 5;
+
+  // ---- work item
+  const int chunk = blockIdx.x;
+  const int unit = chunk / p.RC, rc = chunk - unit * p.RC;
+  const int n = unit / p.S, s = unit - n * p.S;
+  const int w0 = s * 32;
+  const int h0 = rc * p.rows_per_chunk;
+  int h1 = h0 + p.rows_per_chunk;
+  if (h1 > p.H) h1 = p.H;
+  const size_t img_px = (size_t)n * p.H * p.W;
+
+  // ---- this wave's filter slice -> registers: A operand, lane = (row cout = l31, k = 8*hb + j)
+  bf16x8_t wf[9][4];
+  {
+    const char* wbase = p.Wt + ((size_t)(wave * 32 + l31) * 576 + 8 * hb) * 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wf[t][k] = *(const bf16x8_t*)(wbase + (t * 64 + k * 16) * 2);
+  }
+  // accumulator row (cout within the wave's 32) of register r: (r&3) + 8*(r>>2) + 4*hb
+  float bias_r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    bias_r[r] = p.bias ? p.bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] : 0.f;
+
+  // ---- ring staging geometry
+  const int xr = lane >> 3, xpc = lane & 7;
+  auto stage_x = [&](int hrow) {
+    char* slot = lX + ((hrow + 1) & 3) * X_SLOT;
+    const bool row_ok = hrow >= 0 && hrow < p.H;
+#pragma unroll
+    for (int k = 0; k < (X_WI + NW - 1) / NW; ++k) {
+      const int wi = wave + k * NW;
+      if (wi < X_WI) {
+        const int pos = wi * 8 + xr;
+        const int w = w0 - 1 + pos;
+        const bool ok = row_ok && pos < 34 && w >= 0 && w < p.W;
+        const int lc = xpc ^ ((pos >> 1) & 7);
+        const char* g = ok ? p.X + ((img_px + (size_t)hrow * p.W + w) * 64 + lc * 8) * 2 : p.zero_page;
+        glds16(g, slot + wi * 1024);
+      }
+    }
+  };
+  // fragment read geometry: B operand, lane = (col px = l31, k = 8*hb + j); ring position px+dx+1
+  int xbase[3], xsw[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int pos = l31 + d;
+    xbase[d] = pos * 128;
+    xsw[d] = (pos >> 1) & 7;
+  }
+  char* myO = lO + wave * 2048;
+  const bool px_ok = (w0 + l31) < p.W;
+
+  stage_x(h0 - 1);
+  stage_x(h0);
+  stage_x(h0 + 1);
+  for (int h = h0; h < h1; ++h) {
+    __syncthreads();                     // row h+1 landed (vmcnt(0)+barrier); step h-1 done everywhere
+    if (h + 1 < h1) stage_x(h + 2);
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi) {
+      const char* slot = lX + ((h + dyi) & 3) * X_SLOT;
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = (2 * k + hb) ^ xsw[dxi];
+          const bf16x8_t xf = *(const bf16x8_t*)(slot + xbase[dxi] + (c << 4));
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][k], xf, acc, 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: (relu) -> bf16 -> per-wave LDS shuffle -> 16-byte row-segment stores
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[q * 4 + e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      u32x2_t pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      const int slot8 = (2 * q + hb) ^ (l31 & 7);            // 8-byte slot = couts 8q + 4hb .. +3
+      *(u32x2_t*)(myO + l31 * 64 + slot8 * 8) = pk;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const size_t row_px = img_px + (size_t)h * p.W + w0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int id = lane + 64 * r;                           // 128 chunks of 16 B: (px, c16)
+      const int px = id >> 2, c16 = id & 3;
+      const int x7 = px & 7;
+      u32x4_t v;
+      const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
+      const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+      if ((w0 + px) < p.W) {
+        const size_t goff = ((row_px + px) * O + wave * 32 + c16 * 8) * 2;
+        if (p.mask_src) {
+          const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t mw = mk[e], vw = v[e];
+            const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
+            const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
+            const float a = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+            const float b = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+            v[e] = pack_bf16x2(a, b);
+          }
+        }
+        *(u32x4_t*)(p.out + goff) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  (void)px_ok;
+}
+
+// X [N,H,W,64] bf16, Wt [O][576] bf16 -> out [N,H,W,O] bf16 (O = 64 or 128)
+extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, const void* mask_src, void* out,
+                            const void* zero_page, int N, int H, int W, int O, int relu, float mask_scale,
+                            hipStream_t stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || (O != 64 && O != 128)) return -10;
+  ConvC64Params p;
+  p.X = (const char*)X; p.Wt = (const char*)Wt; p.bias = bias; p.mask_src = (const char*)mask_src;
+  p.out = (char*)out; p.zero_page = (const char*)zero_page;
+  p.N = N; p.H = H; p.W = W; p.relu = relu; p.mask_scale = mask_scale;
+  p.S = (W + 31) / 32;
+  const long units = (long)N * p.S;
+  // row chunks: enough workgroups to fill the chip several times over, >= 16 rows each so the
+  // 18 KB register filter load and the 3-row ring prologue amortise
+  int rc = (int)((16L * 256 + units - 1) / units);
+  if (rc > H / 16) rc = H / 16;
+  if (rc < 1) rc = 1;
+  p.rows_per_chunk = (H + rc - 1) / rc;
+  p.RC = (H + p.rows_per_chunk - 1) / p.rows_per_chunk;
+  const long grid = units * p.RC;
+  if (grid > 0x7FFFFFFFL) return -11;
+  if (O == 64) {
+    constexpr int lds = 4 * 40 * 128 + 2 * 2048;
+    hipLaunchKernelGGL(conv_c64_kernel<64>, dim3((unsigned)grid), dim3(128), lds, stream, p);
+  } else {
+    constexpr int lds = 4 * 40 * 128 + 4 * 2048;
+    hipLaunchKernelGGL(conv_c64_kernel<128>, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  }
+  return DTP_CHECK_LAUNCH();
+}

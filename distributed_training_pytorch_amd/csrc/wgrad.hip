@@ -11,7 +11,7 @@
 // * LDS images are XOR-swizzled per k-row (on the global source address, LDS-DMA being
 //   lane-linear) so that the 8 rows x 4 column-groups a half-wave touches per transposed read
 //   fall on 32 distinct 8-byte bank slots (conflict-free; see s_of()).
-// * The huge reduction axis (up to N*50176) is split across workgroups (gridDim.y); partial f32
+// * The huge reduction axis (up to N*50176) is split across workgroups (1-D grid of (z, tile)); partial f32
 //   slabs are summed by wgrad_reduce_kernel, which also applies beta (gradient accumulation) and
 //   casts to the gradient arena's dtype — deterministic, no float atomics
 //   (cdna_hip_programming.md Guideline 12).
@@ -64,7 +64,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
   const int wm = wave / WGN, wn = wave % WGN;
 
   const int ntiles = p.tiles_m * p.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  // 1-D grid over (k-split z, tile) with the tile index fastest, remapped so that each XCD owns a
+  // contiguous run: all tiles (taps x channel blocks) of one k-chunk then run on the SAME XCD at
+  // the same time and share its L2 — the activations are fetched from HBM once, not once per tap
+  // (measured before: TCC hit rate 14 %, FETCH_SIZE 8x the operand bytes).
+  const int nsplit_g = gridDim.x / ntiles;
+  const int pair = xcd_remap(blockIdx.x, gridDim.x);
+  const int zsplit = pair / ntiles;
+  const int tile = pair - zsplit * ntiles;
   const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;   // tm fastest: share the X tile
   const int m0 = tm * BM;
   int n0, tap = 0, c0 = 0;
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
   }
   const int dy = TAPS9 ? tap / 3 - 1 : 0, dx = TAPS9 ? tap % 3 - 1 : 0;
 
-  const int kbeg = blockIdx.y * p.ksteps_per_split;
+  const int kbeg = zsplit * p.ksteps_per_split;
   int kend = kbeg + p.ksteps_per_split;
   if (kend > p.ksteps_total) kend = p.ksteps_total;
 
@@ -197,8 +204,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
   }
 
   // ---------------- epilogue: lane owns dW[m = .. + (lane&15)][n .. n+3]
-  const bool direct = gridDim.y == 1;
-  float* slab = p.partial + (size_t)blockIdx.y * p.M * p.Ntot;
+  const bool direct = nsplit_g == 1;
+  float* slab = p.partial + (size_t)zsplit * p.M * p.Ntot;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * WM + i * 16 + li;
@@ -283,7 +290,7 @@ static int launch_wg(const WgradParams& p0, int nsplit, hipStream_t stream) {
       return -2;
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, nsplit, 1);
+  dim3 grid(p.tiles_m * p.tiles_n * nsplit, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, stream, p);
   return DTP_CHECK_LAUNCH();
 }

@@ -54,7 +54,10 @@ def pick_igemm(M, N, ksteps):
     cfg = order[-1]
     for c in order:
         bm, bn = IGEMM_TILES[c]
-        if _cdiv(M, bm) * _cdiv(N, bn) >= 2 * N_CU:
+        # 256x256 tiles run one workgroup per CU: even a single partial round (196 tiles for
+        # conv5 at batch 128) beats 128x128 tiles by 1.4x (sweep: 1153 vs 832 TF/s)
+        need = N_CU // 2 if bm * bn >= 256 * 256 else 2 * N_CU
+        if _cdiv(M, bm) * _cdiv(N, bn) >= need:
             cfg = c
             break
     bm, bn = IGEMM_TILES[cfg]
@@ -118,6 +121,15 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     return out
 
 
+def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale):
+    """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip)."""
+    rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out),
+                                 ptr(workspace.zero_page(x.device)), N, H, W, O, int(relu), float(mask_scale),
+                                 stream())
+    check(rc, "conv_c64")
+    return out
+
+
 def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
     """y = relu(conv3x3_same(x, w) + bias); x [N,H,W,C] bf16, w [Cout, 9*C] bf16, bias f32 [Cout]."""
     _need(x, BF16, "x")
@@ -136,6 +148,8 @@ def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
         _need(out, BF16, "out")
         if out.numel() != N * H * W * Cout:
             raise ValueError("out size")
+    if C == 64 and Cout in (64, 128) and "igemm" not in _overrides:
+        return _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0)
     return _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0)
 
 
@@ -153,6 +167,8 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
             raise ValueError("mask_src size")
     if out is None:
         out = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
+    if Co == 64 and Cin in (64, 128) and "igemm" not in _overrides:
+        return _conv_c64(dy, wd, None, mask_src, out, N, H, W, Cin, False, mask_scale)
     return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
                   mask_scale, 0.0, 0)
 
