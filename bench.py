@@ -31,11 +31,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DTP_BENCH_BATCH", "128")))
+    ap.add_argument("--batch-per-gpu", type=int, default=int(os.environ.get("DTP_BENCH_BATCH", "256")))
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--grad-dtype", default=os.environ.get("DTP_BENCH_GRAD_DTYPE", "bf16"), choices=["fp32", "bf16"])
-    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--lr", type=float, default=0.001)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -56,8 +56,20 @@ def main():
         opt.step()
         return loss
 
+    # MIOpen's first-call kernel search at a new batch size can take minutes: keep a heartbeat
+    import sys
+    import threading
+    done = threading.Event()
+
+    def beat():
+        t = time.time()
+        while not done.wait(30):
+            print("[bench_stock] warming up (MIOpen find) %.0fs" % (time.time() - t), file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    done.set()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -80,10 +81,16 @@ void* dtp_rccl_create(const void* id_bytes, int rank, int world, int device) {
   ncclUniqueId id;
   std::memcpy(&id, id_bytes, sizeof(id));
   if (ncclCommInitRank(&t->comm, world, id, rank) != ncclSuccess) { delete t; return nullptr; }
-  // high priority: small collectives should not queue behind long compute kernels' tails
+  // Default-priority, non-blocking stream (what ProcessGroupNCCL uses too).  A HIGH-priority comm
+  // stream deadlocked the device on gfx950 / ROCm 7.0 when its event-gated RCCL kernel became
+  // runnable while LDS-heavy compute kernels were resident on the null stream (reproduced with
+  // tests/test_gpu_model.py after a warm-up step; hipDeviceSynchronize never returned), so high
+  // priority is opt-in: DTP_RCCL_STREAM_PRIORITY=high.
   int lo = 0, hi = 0;
   hipDeviceGetStreamPriorityRange(&lo, &hi);
-  if (hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+  const char* pr = std::getenv("DTP_RCCL_STREAM_PRIORITY");
+  const int prio = (pr && pr[0] == 'h') ? hi : 0;
+  if (hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) {
     ncclCommDestroy(t->comm);
     delete t;
     return nullptr;

@@ -134,6 +134,7 @@ class BucketedReducer(object):
         self.pre_ready = None        # optional fn(p): bring an autograd grad into the arena first
         self._cb_queued = False
         self._hooks = []
+        self._ready_ids = set()      # params already counted in this backward pass
         self.stats = dict(launched=0, finalized=0, bytes=0)
 
         gdtype = grad_dtype or (flat_grad.dtype if flat_grad is not None else self.params[0].dtype)
@@ -207,6 +208,14 @@ class BucketedReducer(object):
 
         Autograd hooks call it; fused ops that write straight into the arena call it themselves.
         """
+        # A parameter counts ONCE per pass.  Fused layers notify explicitly right after queueing
+        # their weight-gradient kernels, and autograd's AccumulateGrad node can fire the
+        # post-accumulate hook for the same parameter afterwards (it does even when the Function
+        # returned None for it): counting both would complete a bucket early and start its
+        # all-reduce while later gradients of that bucket are still being written.
+        if id(p) in self._ready_ids:
+            return
+        self._ready_ids.add(id(p))
         if self.pre_ready is not None:
             self.pre_ready(p)
         for b in self._param_buckets[id(p)]:
@@ -258,6 +267,7 @@ class BucketedReducer(object):
                 if self._owns_grads:
                     self._scatter_split_params(b)
             self.stats["finalized"] += 1
+        self._ready_ids.clear()
         for b in self.buckets:
             b.pending = b.expected
             b.work = None

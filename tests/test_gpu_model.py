@@ -201,14 +201,33 @@ def test_native_rccl_transport_world1_and_reducer_over_it():
     crit = SoftmaxCrossEntropy()
     x = torch.randn(8, 3, 32, 32, device="cuda")
     y = torch.randint(0, 3, (8,), device="cuda")
-    a.zero_grad()
-    crit(gpu(x), y).backward()
-    torch.cuda.synchronize()
-    g1 = a.flat_grad.clone()
+    # order of events: every ready notification must come before its bucket's launch, once per
+    # parameter (autograd's AccumulateGrad fires the hook a second time for kernel-written params)
+    trace, _mr, _la = [], red.mark_ready, red._launch
+    red.mark_ready = lambda p: (trace.append(("ready", id(p))), _mr(p))
+    red._launch = lambda b: (trace.append(("launch", b.index)), _la(b))
+
+    def run(poison):
+        a.zero_grad()
+        if poison:                                      # a bucket reduced (read-modify-write on the
+            a.flat_grad.fill_(7.0)                      # comm stream) before its last gradient is
+            torch.cuda.synchronize()                    # written would carry the poison through
+        crit(gpu(x), y).backward()
+        torch.cuda.synchronize()
+        return a.flat_grad.clone()
+
+    g1 = run(True)
     assert red.stats["launched"] == len(red.buckets) and red.stats["finalized"] == 1
+    seen = set()
+    for kind, v in trace:
+        if kind == "ready":
+            seen.add(v)
+        else:
+            assert red.buckets[v].param_ids <= seen, "bucket %d launched before its gradients" % v
+    g2 = run(True)
     a.reducer = None
-    a.zero_grad()
-    crit(gpu(x), y).backward()
-    torch.cuda.synchronize()
-    assert torch.equal(a.flat_grad, g1)                 # reduction over one rank is the identity
+    ref = run(False)
+    for i, p in enumerate(a.params):                    # padding between tensors keeps the poison
+        s = slice(a.offsets[i], a.offsets[i] + p.numel())
+        assert torch.equal(g1[s], ref[s]) and torch.equal(g2[s], ref[s]), a.names[i]
     t.close()

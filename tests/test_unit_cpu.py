@@ -279,3 +279,38 @@ def test_reducer_world1_grads_are_bucket_views_and_survive_set_to_none():
         net(x).sum().backward()                                     # accumulates locally
     for p, r in zip(net.parameters(), ref):
         assert torch.allclose(p.grad, 2 * r)
+
+
+def test_reducer_counts_each_parameter_once_per_pass():
+    """A fused layer notifies explicitly and autograd's AccumulateGrad may fire the hook again for
+    the same parameter: the bucket must not launch until every *distinct* parameter is ready
+    (found on the GPU: early launch = all-reduce racing the remaining weight-gradient kernels)."""
+    class FakeTransport(object):
+        world = 2
+
+        def __init__(self):
+            self.launched = []
+
+        def launch(self, flat):
+            self.launched.append(flat.numel())
+            return None
+
+        def wait(self, handle, flat):
+            pass
+
+    ps = [nn.Parameter(torch.zeros(10)) for _ in range(4)]
+    flat = torch.zeros(64 * 4)
+    tr = FakeTransport()
+    red = BucketedReducer(ps, flat_grad=flat, flat_offsets=[0, 64, 128, 192], transport=tr,
+                          bucket_cap_mb=1, first_bucket_mb=1, split_large_mb=0)
+    assert len(red.buckets) == 1
+    for p in (ps[3], ps[3], ps[2], ps[2], ps[3]):
+        red.mark_ready(p)
+    assert tr.launched == []                                  # 5 notifications, 2 distinct params
+    red.mark_ready(ps[1])
+    red.mark_ready(ps[0])
+    assert len(tr.launched) == 1
+    red.finalize_now()
+    for p in ps:                                              # next pass starts from a clean slate
+        red.mark_ready(p)
+    assert len(tr.launched) == 2
