@@ -32,6 +32,8 @@ def conv_set(C, Co, HW):
 conv_set(256, 256, 56)    # 8-phase igemm (fprop/dgrad) + 256x256 TT wgrad
 conv_set(64, 64, 224)     # 256x64 igemm + column-strip wgrad_c64
 conv_set(128, 128, 112)   # 256x128 pipelined igemm + 128x128 TT wgrad
+conv_set(64, 128, 112)    # conv_c64<128> fprop, 256x64 igemm dgrad, wgrad_c64<128>
+conv_set(512, 512, 28)    # 8-phase igemm + 256x256 TT wgrad, deep K
 x = torch.randn(N, 3, 224, 224, device="cuda")
 w1 = (torch.randn(64, 27, device="cuda") * 0.27).to(BF16)
 y = k.conv1_fprop(x, w1, torch.zeros(64, device="cuda"))

@@ -24,7 +24,7 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
                                                      ctypes.c_size_t, ctypes.c_long, ctypes.c_ulonglong)
 
 _SIGS = {
-    "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_float, c_float, c_ull, c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -35,7 +35,9 @@ _SIGS = {
     "dtp_wgrad_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
     "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "dtp_maxpool2x2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "dtp_maxpool2x2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                           ctypes.POINTER(c_int), c_void_p],
+    "dtp_colsum_parts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "dtp_avgpool_flatten_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_avgpool_flatten_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_colsum": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],

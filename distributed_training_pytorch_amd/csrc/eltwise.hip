@@ -94,6 +94,51 @@ extern "C" int dtp_colsum(const void* x, void* out, float* workspace, int ws_flo
   return DTP_CHECK_LAUNCH();
 }
 
+// f32 variant of pass 1 for partial rows emitted by producer epilogues (igemm / maxpool backward)
+__global__ void colsum_f32_pass1_kernel(const float* __restrict__ part_in, float* __restrict__ part, int rows, int C,
+                                        int rpb) {
+  const int lanes = C < 256 ? C : 256;
+  const int rr_n = 256 / lanes;
+  const int cl = threadIdx.x % lanes, rr = threadIdx.x / lanes;
+  const int r0 = blockIdx.x * rpb;
+  int r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  __shared__ float red[256];
+  for (int c0 = 0; c0 < C; c0 += lanes) {
+    const int c = c0 + cl;
+    float acc = 0.f;
+    if (c < C && rr < rr_n)
+      for (int r = r0 + rr; r < r1; r += rr_n) acc += part_in[(size_t)r * C + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rr == 0 && c < C) {
+      for (int k = 1; k < rr_n; ++k) acc += red[k * lanes + cl];
+      part[(size_t)blockIdx.x * C + c] = acc;
+    }
+    __syncthreads();
+  }
+}
+
+// out[:Cvalid] = beta*out + sum_r part_in[r][:]; part_in [nparts][C] f32 written by a producer's
+// epilogue; workspace >= 128*C floats (used when nparts > 128)
+extern "C" int dtp_colsum_parts(const float* part_in, int nparts, int C, int Cvalid, void* out, float* workspace,
+                                int ws_floats, int out_fp32, float beta, hipStream_t s) {
+  if (nparts <= 0 || C <= 0 || Cvalid > C) return -10;
+  const float* src = part_in;
+  int nb = nparts;
+  if (nparts > 128) {
+    nb = ws_floats / C;
+    if (nb > 128) nb = 128;
+    if (nb < 1) return -11;
+    const int rpb = (nparts + nb - 1) / nb;
+    nb = (nparts + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_f32_pass1_kernel, dim3(nb), dim3(256), 0, s, part_in, workspace, nparts, C, rpb);
+    src = workspace;
+  }
+  hipLaunchKernelGGL(colsum_pass2_kernel, dim3((Cvalid + 63) / 64), dim3(256), 0, s, src, nb, C, Cvalid, out,
+                     out_fp32, beta);
+  return DTP_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------------------------ transpose
 // out[b][c][r] = in[b][r][c], 64x64 tiles through LDS (+1 padding), batch offsets may be negative.
 __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int R, int Cc,

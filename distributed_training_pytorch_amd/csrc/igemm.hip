@@ -31,6 +31,8 @@ struct IgemmParams {
   const char* mask_src;   // bf16 [M][ldo]: output is multiplied by (mask_src > 0) * mask_scale
   char* out;              // bf16 or f32 [M][ldo]
   float* partial;         // split-K slabs [z][M][Ncols] f32 (when gridDim.y > 1)
+  float* colsum_part;     // optional [tiles_m][Ncols] f32: column sums of the final bf16 output tile
+                          // (bias gradient of the layer that consumes this output as its dY)
   const char* zero_page;
   int M, Ncols, C;
   int H, W;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   {
     constexpr int CPR = BN / 8;                 // 16-B chunks per C row
     constexpr int TOTAL = BM * CPR;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int id = tid; id < TOTAL; id += T) {
       const int pl = id / CPR;
       const int q = id - pl * CPR;
@@ -504,6 +507,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         }
       }
       *(u32x4_t*)(p.out + goff) = v;
+      if (p.colsum_part) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          cs[2 * e] += __uint_as_float(v[e] << 16);
+          cs[2 * e + 1] += __uint_as_float(v[e] & 0xFFFF0000u);
+        }
+      }
+    }
+    if (p.colsum_part) {   // kernel-uniform
+      // T % CPR == 0: a thread keeps the same 8-column chunk q for all its rows; fold the T/CPR
+      // row-groups through LDS (the C image is dead after the barrier), one partial row per tile
+      constexpr int G = T / CPR;
+      static_assert(T % CPR == 0 && BN <= T, "colsum epilogue geometry");
+      __syncthreads();
+      float* red = (float*)smem;
+      const int q = tid % CPR, g = tid / CPR;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[g * BN + q * 8 + e] = cs[e];
+      __syncthreads();
+      if (tid < BN && n0 + tid < p.Ncols) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < G; ++k) s += red[k * BN + tid];
+        p.colsum_part[(size_t)tm * p.Ncols + n0 + tid] = s;
+      }
     }
   }
 }
@@ -551,7 +579,8 @@ static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
 }
 
 extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, const void* mask_src, void* out,
-                            float* partial, const void* zero_page, int M, int Ncols, int C, int taps, int H,
+                            float* partial, float* colsum_part, const void* zero_page, int M, int Ncols, int C,
+                            int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, int nsplit, int cfg, hipStream_t stream) {
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & 63)) return -10;          // K chunks are 64 wide
@@ -562,6 +591,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   IgemmParams p;
   p.A = (const char*)A; p.B = (const char*)B; p.bias = bias; p.mask_src = (const char*)mask_src;
   p.out = (char*)out; p.partial = partial; p.zero_page = (const char*)zero_page;
+  p.colsum_part = colsum_part;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
   p.ksteps_total = taps * (C >> 6);
@@ -570,6 +600,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.ksteps_per_split = (p.ksteps_total + nsplit - 1) / nsplit;
   nsplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
   if (nsplit > 1 && partial == nullptr) return -15;
+  if (colsum_part && (nsplit > 1 || out_fp32)) return -17;   // only the bf16 C-image epilogue emits it
   int rc;
   const bool t9 = taps == 9;
 #define DTP_IG(BM_, BN_, WGM_, WGN_, PIPE_)                                     \

@@ -45,10 +45,15 @@ __global__ void maxpool2x2_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __re
 
 // dx = dy routed to the FIRST maximal element of each window (torch's tie rule), optionally
 // multiplied by (x > 0): the ReLU that precedes the pool in every VGG block.
+// colsum_part (optional, [gridDim.x][C] f32): per-block column sums of dx — the bias gradient of
+// the conv that produced x, for free while dx is in registers (needs 256 % (C/8) == 0 so that a
+// thread keeps its channel chunk over the grid-stride loop).
 __global__ void maxpool2x2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                      bf16_t* __restrict__ dx, int N, int H, int W, int C, int relu_mask) {
+                                      bf16_t* __restrict__ dx, int N, int H, int W, int C, int relu_mask,
+                                      float* __restrict__ colsum_part) {
   const int OH = H >> 1, OW = W >> 1, CV = C >> 3;
   const size_t total = (size_t)N * OH * OW * CV;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
@@ -74,6 +79,7 @@ __global__ void maxpool2x2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t
       const float gv = (relu_mask && !(m > 0.f)) ? 0.f : g[e];
       ra[e] = arg == 0 ? gv : 0.f; rb[e] = arg == 1 ? gv : 0.f;
       rc[e] = arg == 2 ? gv : 0.f; rd[e] = arg == 3 ? gv : 0.f;
+      cs[e] += gv;                 // exactly one element of the window receives gv
     }
     u32x4_t oa, ob, oc, od;
 #pragma unroll
@@ -87,6 +93,18 @@ __global__ void maxpool2x2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t
     *(u32x4_t*)(dx + base + o01) = ob;
     *(u32x4_t*)(dx + base + o10) = oc;
     *(u32x4_t*)(dx + base + o11) = od;
+  }
+  if (colsum_part) {   // kernel-uniform
+    __shared__ float red[256 * 8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = cs[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const int cv = c >> 3, e = c & 7;
+      float s = 0.f;
+      for (int t = cv; t < 256; t += CV) s += red[t * 8 + e];
+      colsum_part[(size_t)blockIdx.x * C + c] = s;
+    }
   }
 }
 
@@ -167,16 +185,25 @@ extern "C" int dtp_maxpool2x2_fwd(const void* x, void* y, int N, int H, int W, i
   return DTP_CHECK_LAUNCH();
 }
 
+// colsum_part: null, or room for max_parts*C floats; returns the number of partial rows written
+// through *nparts (0 when not requested)
 extern "C" int dtp_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                                  int relu_mask, hipStream_t s) {
+                                  int relu_mask, float* colsum_part, int max_parts, int* nparts, hipStream_t s) {
   if (N <= 0 || H < 2 || W < 2 || (C & 7)) return -10;
+  if (nparts) *nparts = 0;
+  if (colsum_part && (max_parts < 1 || (256 % (C >> 3)) != 0)) return -11;
   if ((H & 1) || (W & 1)) {
     hipLaunchKernelGGL(zero_tail_kernel, dim3(grid_for((size_t)N * H * W * C)), dim3(256), 0, s, (bf16_t*)dx, N, H,
                        W, C);
   }
   const size_t work = (size_t)N * (H / 2) * (W / 2) * (C / 8);
-  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_for(work)), dim3(256), 0, s, (const bf16_t*)x,
-                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, relu_mask);
+  int grid = grid_for(work);
+  if (colsum_part) {
+    if (grid > max_parts) grid = max_parts;
+    if (nparts) *nparts = grid;
+  }
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)x,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, relu_mask, colsum_part);
   return DTP_CHECK_LAUNCH();
 }
 

@@ -6,6 +6,8 @@ launches on the caller's current HIP stream.  Tensors are internal-layout: activ
 ``[N, H, W, C]``, conv weights ``[Cout, 9*Cin]`` (tap-major, channel-minor), linear weights
 ``[out, in]``.
 """
+import ctypes as _ctypes
+
 import torch
 
 from .. import _lib
@@ -106,14 +108,73 @@ def pick_wgrad(M, C, taps, ksteps):
     return cfg, max(1, nsplit)
 
 
+class _ColsumSlot(object):
+    """Column sums that a producer kernel left behind for the NEXT backward function.
+
+    The bias gradient of a layer is the column sum of its dY, and dY is the output of an earlier
+    kernel of the same backward pass (the next layer's data-gradient with the ReLU mask fused, or
+    the max-pool backward).  Those kernels fold their output tile into per-workgroup f32 partial
+    rows while it is still in registers, so the 1.6 GB (conv1_2, batch 256) re-read of dY by a
+    separate column-sum kernel disappears.  One slot: the producer overwrites it, the consumer
+    takes it only when its dY is *the same tensor* (the slot keeps the producer's output alive, so
+    an equal data_ptr cannot be a recycled allocation)."""
+
+    def __init__(self):
+        self.tensor = None
+        self.parts = None
+        self.nparts = 0
+        self.C = 0
+
+    def put(self, tensor, parts, nparts, C):
+        self.tensor, self.parts, self.nparts, self.C = tensor, parts, nparts, C
+
+    def take(self, dy2d_or_4d, C):
+        t = self.tensor
+        self.tensor = None
+        if (t is None or t.data_ptr() != dy2d_or_4d.data_ptr() or t.numel() != dy2d_or_4d.numel()
+                or self.C != C or t.device != dy2d_or_4d.device):
+            return None
+        return self.parts, self.nparts
+
+
+colsum_slot = _ColsumSlot()
+fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
+
+
+def colsum_parts(parts, nparts, C, out, n_valid=None, beta=0.0):
+    """out[:n_valid] = beta*out + sum of the producer's partial rows parts[nparts][C]."""
+    nv = C if n_valid is None else n_valid
+    if out.numel() != nv or out.dtype not in (torch.float32, BF16) or parts.numel() < nparts * C:
+        raise ValueError("colsum_parts: bad shapes")
+    ws = workspace.get("colsum", 1024 * max(C, 64), torch.float32, parts.device)
+    rc = _lib.hip().dtp_colsum_parts(ptr(parts), nparts, C, nv, ptr(out), ptr(ws), ws.numel(),
+                                     int(out.dtype == torch.float32), float(beta), stream())
+    check(rc, "colsum_parts")
+    return out
+
+
+def bias_grad(dy2d, out, n_valid=None, beta=0.0):
+    """Bias gradient = column sums of dY: from the producer's partial rows when the kernel that
+    wrote dY left them (see _ColsumSlot), else with the two-pass column-sum kernel."""
+    got = colsum_slot.take(dy2d, dy2d.shape[-1]) if fuse_colsum else None
+    if got is not None:
+        return colsum_parts(got[0], got[1], dy2d.shape[-1], out, n_valid, beta)
+    return colsum(dy2d, out, n_valid, beta)
+
+
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
-           mask_scale, drop_p, seed):
+           mask_scale, drop_p, seed, want_colsum=False):
     ksteps = taps * (C // 64)
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
     partial = None
     if nsplit > 1:
         partial = workspace.get("igemm_partial", nsplit * M * Ncols, torch.float32, A.device)
-    rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial),
+    cs_part = None
+    if want_colsum and fuse_colsum and nsplit == 1 and not out_fp32 and ldo == Ncols:
+        nparts = _cdiv(M, IGEMM_TILES[cfg][0])
+        cs_part = workspace.get("colsum_parts", nparts * Ncols, torch.float32, A.device)
+        colsum_slot.put(out, cs_part, nparts, Ncols)
+    rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial), ptr(cs_part),
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  nsplit, cfg, stream())
@@ -169,8 +230,9 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
         out = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
     if Co == 64 and Cin in (64, 128) and "igemm" not in _overrides:
         return _conv_c64(dy, wd, None, mask_src, out, N, H, W, Cin, False, mask_scale)
+    # a masked data-gradient is the dY of the convolution below: leave its column sums behind
     return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
-                  mask_scale, 0.0, 0)
+                  mask_scale, 0.0, 0, want_colsum=mask_src is not None)
 
 
 def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None):
@@ -286,8 +348,16 @@ def maxpool2x2_bwd(x, dy, relu_mask=False):
     if tuple(dy.shape) != (N, H // 2, W // 2, C):
         raise ValueError("maxpool2x2_bwd: dy shape %s" % (tuple(dy.shape),))
     dx = torch.empty_like(x)
-    check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask), stream()),
-          "maxpool_bwd")
+    cs_part, max_parts = None, 0
+    if fuse_colsum and 256 % (C // 8) == 0 and H % 2 == 0 and W % 2 == 0:
+        # dx is the dY of the convolution that produced x: leave its column sums behind
+        max_parts = 1024
+        cs_part = workspace.get("colsum_parts", max_parts * C, torch.float32, x.device)
+    nparts = _ctypes.c_int(0)
+    check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask), ptr(cs_part),
+                                        max_parts, _ctypes.byref(nparts), stream()), "maxpool_bwd")
+    if cs_part is not None and nparts.value > 0:
+        colsum_slot.put(dx, cs_part, nparts.value, C)
     return dx
 
 

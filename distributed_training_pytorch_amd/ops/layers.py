@@ -84,7 +84,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         Co = weight.shape[0]
         K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         if ctx.has_bias:
-            K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
             arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
         dx = None
@@ -164,7 +164,7 @@ class _ConvFirstFn(torch.autograd.Function):
                 dst.copy_(g)
             else:
                 dst.add_(g)
-            K.colsum(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
         return None, None, None, None
@@ -291,7 +291,7 @@ class _LinearFn(torch.autograd.Function):
             scale = 1.0 / (1.0 - layer.drop_p) if (layer.drop_p > 0 and layer.training) else 1.0
             dy = K.relu_mask(dy, y, scale)
         K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
-        K.colsum(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
+        K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
         dx = None

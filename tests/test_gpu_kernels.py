@@ -401,3 +401,57 @@ def test_conv3x3_8phase_schedule(shape):
         _close(outs[0], ref, 2e-2, 2e-2, "8phase%s split%d" % (shape, nsplit))
         for o in outs[1:]:
             assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16])
+def test_fused_bias_grad_from_dgrad_epilogue(cfg):
+    """The masked data-gradient kernel leaves per-tile column sums of its output behind; the
+    consumer's bias gradient built from them equals the column sum of the stored bf16 tensor."""
+    k = _k()
+    torch.manual_seed(11)
+    N, H, W, C, Co = 3, 18, 14, 192, 128          # M = 756: row tail in every tile size
+    dy = _rand(N, H, W, Co)
+    wd = _rand(C, 9 * Co, scale=(2.0 / (9 * Co)) ** 0.5)
+    xmask = _rand(N, H, W, C)
+    k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)
+    try:
+        dx = k.conv3x3_dgrad(dy, wd, mask_src=xmask)
+    finally:
+        k._overrides.pop("igemm")
+    assert k.colsum_slot.tensor is dx
+    parts, nparts = k.colsum_slot.parts, k.colsum_slot.nparts
+    for dt in (torch.float32, BF16):
+        out = torch.full((C,), 3.0, device="cuda", dtype=dt)
+        k.bias_grad(dx.view(-1, C), out, beta=1.0)
+        ref = 3.0 + dx.float().view(-1, C).sum(0)
+        _close(out, ref, 1e-2 if dt == BF16 else 1e-5, 2e-2 if dt == BF16 else 1e-4, "fused colsum cfg%d" % cfg)
+        k.colsum_slot.put(dx, parts, nparts, C)     # re-arm for the second dtype
+    k.colsum_slot.take(dx, C)
+    # a different tensor must NOT pick the slot up
+    k.colsum_slot.put(dx, parts, nparts, C)
+    other = dx.clone()
+    assert k.colsum_slot.take(other.view(-1, C), C) is None and k.colsum_slot.tensor is None
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 28, 20, 128), (2, 8, 8, 512), (4, 112, 112, 64)])
+def test_fused_bias_grad_from_maxpool_backward(shape):
+    k = _k()
+    torch.manual_seed(12)
+    N, H, W, C = shape
+    x = _rand(N, H, W, C)
+    dy = _rand(N, H // 2, W // 2, C)
+    dx = k.maxpool2x2_bwd(x, dy, relu_mask=True)
+    assert k.colsum_slot.tensor is dx
+    out = torch.empty(C, device="cuda")
+    k.bias_grad(dx.view(-1, C), out)
+    assert k.colsum_slot.tensor is None
+    _close(out, dx.float().view(-1, C).sum(0), 1e-5, 1e-3, "pool colsum %s" % (shape,))
+    k.fuse_colsum = False
+    try:
+        dx2 = k.maxpool2x2_bwd(x, dy, relu_mask=True)
+        out2 = torch.empty(C, device="cuda")
+        k.bias_grad(dx2.view(-1, C), out2)
+    finally:
+        k.fuse_colsum = True
+    assert torch.equal(dx, dx2)
+    _close(out, out2, 1e-5, 1e-3, "pool colsum vs stand-alone %s" % (shape,))

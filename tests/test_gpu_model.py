@@ -231,3 +231,36 @@ def test_native_rccl_transport_world1_and_reducer_over_it():
         s = slice(a.offsets[i], a.offsets[i] + p.numel())
         assert torch.equal(g1[s], ref[s]) and torch.equal(g2[s], ref[s]), a.names[i]
     t.close()
+
+
+def test_fused_bias_grads_match_standalone_colsum():
+    """Whole model: bias gradients assembled from producer-epilogue partial sums (dgrad / pool
+    backward) equal the ones from the stand-alone column-sum kernel; weight grads are untouched."""
+    from distributed_training_pytorch_amd.ops import kernels as K
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    _, gpu = _models(seed=7)
+    a = gpu.param_arena
+    crit = SoftmaxCrossEntropy()
+    torch.manual_seed(8)
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 3, (8,), device="cuda")
+
+    def run():
+        a.zero_grad()
+        crit(gpu(x), y).backward()
+        torch.cuda.synchronize()
+        return a.flat_grad.clone()
+
+    fused = run()
+    K.fuse_colsum = False
+    try:
+        plain = run()
+    finally:
+        K.fuse_colsum = True
+    for i, (n, p) in enumerate(zip(a.names, a.params)):
+        s = slice(a.offsets[i], a.offsets[i] + p.numel())
+        if n.endswith("weight"):
+            assert torch.equal(fused[s], plain[s]), n
+        else:
+            ref = plain[s].abs().max().item()
+            assert (fused[s] - plain[s]).abs().max().item() <= 1e-4 * ref + 1e-7, n
