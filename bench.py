@@ -76,6 +76,7 @@ def main():
         return loss
 
     def fence():
+        torch.cuda.synchronize()          # drain compute + gradient-comm streams before the barrier
         if world > 1:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
@@ -109,7 +110,8 @@ def main():
                        "global_batch": global_batch, "image_size": args.image_size,
                        "seq_len": None, "parallelism": "dp%d" % world,
                        "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights",
-                       "grad_dtype": args.grad_dtype}}), flush=True)
+                       "grad_dtype": args.grad_dtype,
+                       "grad_transport": type(dp.reducer.transport).__name__}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

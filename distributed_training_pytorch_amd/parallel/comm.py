@@ -61,6 +61,8 @@ def all_reduce_scalars(values, op="sum"):
                      else torch.float32, device=comm_device())
     if op == "sum":
         all_reduce_sum_(t)
+    elif op == "min":
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
     else:
         all_reduce_max_(t)
     return [float(v) for v in t.cpu().tolist()]

@@ -42,12 +42,34 @@ class DataParallel(nn.Module):
 
     @staticmethod
     def _pick_transport(device):
-        if device.type == "cuda" and comm.is_dist() and comm.world_size() > 1:
-            try:
-                from .rccl_native import NativeRcclTransport
-                return NativeRcclTransport()
-            except Exception:
-                pass
+        """Native RCCL transport (own communicator + comm stream, C++) on GPUs, the
+        ``torch.distributed`` process group otherwise.  ``DTP_TRANSPORT=torch|native`` forces one (default: native when it comes up everywhere).
+        All ranks must end up with the same kind: the outcome of the native set-up (communicator
+        creation plus one self-checked all-reduce) is agreed on through the process group before
+        anyone uses it."""
+        import os
+        want = os.environ.get("DTP_TRANSPORT", "auto").lower()
+        if device.type != "cuda" or not comm.is_dist() or comm.world_size() == 1 or want == "torch":
+            return TorchPGTransport()
+        native, ok = None, 1.0
+        try:
+            from .rccl_native import NativeRcclTransport
+            native = NativeRcclTransport()
+            probe = torch.full((256,), float(comm.rank() + 1), device=device)
+            native.wait(native.launch(probe), probe)
+            torch.cuda.current_stream().synchronize()
+            expect = (comm.world_size() + 1) / 2.0            # mean of 1..world
+            if not bool(((probe - expect).abs() < 1e-5).all()):
+                ok = 0.0
+        except Exception:
+            ok = 0.0
+        agreed = comm.all_reduce_scalars([ok], op="min")[0]
+        if agreed >= 1.0:
+            return native
+        if native is not None:
+            native.close()
+        if want == "native":
+            raise RuntimeError("DTP_TRANSPORT=native but the RCCL transport did not come up on every rank")
         return TorchPGTransport()
 
     def sync_module_states(self):
