@@ -26,7 +26,7 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
 _SIGS = {
     "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_float, c_ull, c_int, c_int, c_void_p],
+                     c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],

@@ -42,6 +42,7 @@ struct IgemmParams {
   float mask_scale;
   float drop_p;
   unsigned long long seed;
+  const unsigned long long* seed_ptr;   // optional device-resident base seed (hipGraph replay): seed += *seed_ptr
   int ksteps_total;
   int ksteps_per_split;
   int tiles_m, tiles_n;
@@ -449,6 +450,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   __syncthreads();   // all waves finished reading the staging buffers
   {
     const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const unsigned long long seed = (p.drop_p > 0.f && p.seed_ptr) ? p.seed + *p.seed_ptr : p.seed;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int nl = wn * WN + j * 16 + cq;
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
           if (p.relu) x = fmaxf(x, 0.f);
           if (p.drop_p > 0.f) {
             const uint64_t idx = (uint64_t)(m0 + pl) * (uint64_t)p.Ncols + (uint64_t)(n0 + nl + e);
-            x = rng_uniform(p.seed, idx) >= p.drop_p ? x * keep_scale : 0.f;
+            x = rng_uniform(seed, idx) >= p.drop_p ? x * keep_scale : 0.f;
           }
           v[e] = x;
         }
@@ -541,7 +543,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
 __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ partial, int nsplit, int M, int Ncols,
                                            const float* __restrict__ bias, const bf16_t* __restrict__ mask_src,
                                            void* __restrict__ out, int ldo, int out_fp32, int relu,
-                                           float mask_scale, float drop_p, unsigned long long seed) {
+                                           float mask_scale, float drop_p, unsigned long long seed,
+                                           const unsigned long long* seed_ptr) {
+  if (drop_p > 0.f && seed_ptr) seed += *seed_ptr;
   const size_t total = (size_t)M * Ncols;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -582,7 +586,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             float* partial, float* colsum_part, const void* zero_page, int M, int Ncols, int C,
                             int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
-                            float drop_p, unsigned long long seed, int nsplit, int cfg, hipStream_t stream) {
+                            float drop_p, unsigned long long seed, const void* seed_ptr, int nsplit, int cfg,
+                            hipStream_t stream) {
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & 63)) return -10;          // K chunks are 64 wide
   if (taps != 1 && taps != 9) return -11;
   if (taps == 9 && (H <= 0 || W <= 0 || M % (H * W) != 0)) return -12;
@@ -594,6 +599,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.colsum_part = colsum_part;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
+  p.seed_ptr = (const unsigned long long*)seed_ptr;
   p.ksteps_total = taps * (C >> 6);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > p.ksteps_total) nsplit = p.ksteps_total;
@@ -627,7 +633,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, nsplit, M, Ncols,
-                       bias, (const bf16_t*)mask_src, out, ldo, out_fp32, relu, mask_scale, drop_p, seed);
+                       bias, (const bf16_t*)mask_src, out, ldo, out_fp32, relu, mask_scale, drop_p, seed,
+                       (const unsigned long long*)seed_ptr);
     return DTP_CHECK_LAUNCH();
   }
   return 0;

@@ -1,0 +1,110 @@
+"""Whole-step hipGraph capture: ``zero_grad + forward + loss + backward + optimizer.step`` of a
+fused model becomes ONE ``hipGraphLaunch``.
+
+Why: at the reference's default per-GPU batch (4, ``main.py:15`` / ``run.sh:10``) a VGG16 step is
+~150 kernel launches of a few microseconds each — the GPU idles between them while Python,
+autograd and ctypes issue the next one (the reference never captures anything).
+All kernels of this framework take explicit HIP streams and static workspaces, so the whole step
+is capturable with ``torch.cuda.graph`` (PyTorch-ROCm records it into a hipGraph).
+
+What is frozen at capture and how it is kept correct on replay:
+  * kernel arguments (learning rate, momentum, beta flags, tile choices): the step is re-captured
+    when the optimizer's hyper-parameters change (e.g. a MultiStepLR milestone);
+  * the dropout seed: read from device memory (``Linear.device_seed``) and advanced by a captured
+    add, so every replay draws a fresh mask;
+  * input batches: copied into static device buffers before each replay;
+  * the bf16 working copy of the weights: written by the captured fused optimizer; a
+    ``load_state_dict`` / external parameter edit is detected through the parameters' version
+    counters and triggers a re-capture.
+Gradient all-reduce is not captured in this version: with world size > 1 the step runs eagerly.
+"""
+import torch
+
+from ..ops.layers import Linear
+
+
+class GraphedTrainStep(object):
+    _SEED_STEP = 0x5851F42D4C957F2D & (2 ** 62 - 1)
+
+    def __init__(self, model, criterion, optimizer, warmup=2, enabled=True):
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.raw = getattr(model, "module", model)
+        self.arena = getattr(self.raw, "param_arena", None)
+        self.warmup = int(warmup)
+        self.graph = None
+        self._key = None
+        self.replays = 0
+        self.captures = 0
+        world = getattr(getattr(model, "reducer", None), "world", 1)
+        self.enabled = (bool(enabled) and torch.cuda.is_available() and self.arena is not None and world == 1
+                        and getattr(optimizer, "graph_safe", False))
+        self._seed = None
+        self._eager_left = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _hyper_key(self, x, y):
+        groups = tuple(tuple(sorted((k, repr(v)) for k, v in g.items() if k != "params"))
+                       for g in self.optimizer.param_groups)
+        return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, groups, self.raw.training)
+
+    def _eager(self, x, y):
+        self.optimizer.zero_grad()
+        loss = self.criterion(self.model(x), y)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _attach_seed(self, device):
+        if self._seed is None:
+            self._seed = torch.zeros(1, dtype=torch.int64, device=device)
+            self._seed.fill_(torch.initial_seed() & (2 ** 62 - 1))
+        for m in self.raw.modules():
+            if isinstance(m, Linear):
+                m.device_seed = self._seed
+
+    def _capture(self, x, y):
+        self.x_static = torch.empty_like(x)
+        self.y_static = torch.empty_like(y)
+        self.x_static.copy_(x)
+        self.y_static.copy_(y)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        steps_before = getattr(self.optimizer, "_steps", None)
+        with torch.cuda.graph(g):
+            self._seed.add_(self._SEED_STEP)
+            self.loss_static = self._eager(self.x_static, self.y_static)
+        if steps_before is not None:       # capture ran the Python of step() once without executing it
+            self.optimizer._steps = steps_before
+        self.graph = g
+        self.captures += 1
+        self._versions = self.arena._versions()
+
+    # ------------------------------------------------------------------ the step
+    def __call__(self, x, y):
+        """One optimizer step on batch (x, y); returns the (device-resident) loss.  The first
+        ``warmup`` calls after a (re)configuration run eagerly — they size every workspace, build
+        the derived weight layouts and take the optimizer past its state-initialising step — the
+        next call captures, and every later one is a single graph launch."""
+        if not self.enabled or not x.is_cuda:
+            return self._eager(x, y)
+        self._attach_seed(x.device)
+        key = self._hyper_key(x, y)
+        if key != self._key or (self.graph is not None and self.arena._versions() != self._versions):
+            self.graph, self._key, self._eager_left = None, key, max(1, self.warmup)
+        if self.graph is None:
+            if self._eager_left > 0:
+                self._eager_left -= 1
+                self._seed.add_(self._SEED_STEP)
+                return self._eager(x, y)
+            self.arena.refresh_lp()
+            self._capture(x, y)
+        else:
+            self.x_static.copy_(x, non_blocking=True)
+            self.y_static.copy_(y, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        # host-side bookkeeping that the eager path does per step
+        if hasattr(self.optimizer, "_steps"):
+            self.optimizer._steps += 1
+        self.arena.lp_epoch += 1
+        return self.loss_static

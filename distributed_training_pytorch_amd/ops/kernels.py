@@ -163,7 +163,7 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
-           mask_scale, drop_p, seed, want_colsum=False):
+           mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None):
     ksteps = taps * (C // 64)
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
     partial = None
@@ -177,7 +177,7 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial), ptr(cs_part),
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
-                                 nsplit, cfg, stream())
+                                 ptr(seed_ptr), nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
@@ -235,7 +235,7 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
                   mask_scale, 0.0, 0, want_colsum=mask_src is not None)
 
 
-def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None):
+def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None, seed_ptr=None):
     """y = x @ w.T (+bias)(relu)(dropout); x [M,K] bf16, w [Nout,K] bf16."""
     _need(x, BF16, "x")
     _need(w, BF16, "w")
@@ -249,7 +249,10 @@ def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, 
         raise ValueError("bf16 output needs out_features % 8 == 0 (use out_fp32)")
     if out is None:
         out = torch.empty((M, Nout), dtype=torch.float32 if out_fp32 else BF16, device=x.device)
-    return _igemm(x, w, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed)
+    if seed_ptr is not None and (seed_ptr.dtype != torch.int64 or not seed_ptr.is_cuda or seed_ptr.numel() < 1):
+        raise ValueError("seed_ptr must be a CUDA int64 tensor")
+    return _igemm(x, w, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed,
+                  seed_ptr=seed_ptr)
 
 
 def linear_dgrad(dy, wt, ld_dy=None, mask_src=None, mask_scale=1.0, out=None):

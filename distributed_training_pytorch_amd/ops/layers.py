@@ -266,10 +266,10 @@ class AvgPoolFlatten(nn.Module):
 # =============================================================================== linear
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, layer, drop_p, seed):
+    def forward(ctx, x, weight, bias, layer, drop_p, seed, seed_ptr=None):
         arena = _arena_of(layer)
         y = K.linear_fwd(x, arena.lp(weight), bias.detach(), relu=layer.relu, drop_p=drop_p, seed=seed,
-                         out_fp32=layer.out_fp32)
+                         out_fp32=layer.out_fp32, seed_ptr=seed_ptr)
         ctx.layer = layer
         ctx.in_scale = layer._input_mask_scale()
         ctx.save_for_backward(x, y, weight, bias)
@@ -298,7 +298,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class Linear(FusedLayer):
@@ -316,6 +316,10 @@ class Linear(FusedLayer):
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         self.bias = nn.Parameter(torch.zeros(out_features))
         nn.init.normal_(self.weight, 0, 0.01)
+        # hipGraph replay: kernel arguments are frozen at capture, so the dropout seed must come
+        # from device memory (engine.graph.GraphedTrainStep advances it inside the graph)
+        self.device_seed = None
+        self._seed_salt = next(_seed_counter) * 0x9E3779B97F4A7C15 & (2 ** 62 - 1)
 
     def _input_mask_scale(self):
         if self.input_is_relu_out and self.input_drop_p > 0 and self.training:
@@ -331,6 +335,8 @@ class Linear(FusedLayer):
                 y = F.dropout(y, self.drop_p, self.training)
             return y
         p = self.drop_p if self.training else 0.0
+        if p > 0 and self.device_seed is not None:
+            return _LinearFn.apply(x, self.weight, self.bias, self, p, self._seed_salt, self.device_seed)
         seed = (torch.initial_seed() * 1000003 + next(_seed_counter)) & (2 ** 63 - 1) if p > 0 else 0
         return _LinearFn.apply(x, self.weight, self.bias, self, p, seed)
 

@@ -31,6 +31,7 @@ def _arena_from(model_or_arena):
 
 class _FusedBase(torch.optim.Optimizer):
     _state_keys = ()
+    graph_safe = False     # True: step() passes nothing that changes from step to step by value
 
     def __init__(self, model, defaults):
         self.arena = _arena_from(model)
@@ -86,6 +87,7 @@ class _FusedBase(torch.optim.Optimizer):
 
 class FusedSGD(_FusedBase):
     _state_keys = ("momentum_buffer",)
+    graph_safe = True      # (after the first, state-initialising step; lr changes force a re-capture)
 
     def __init__(self, model, lr=0.1, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
         if nesterov and (momentum <= 0 or dampening != 0):

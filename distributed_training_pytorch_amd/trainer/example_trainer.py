@@ -98,6 +98,9 @@ class ExampleTrainer(Trainer):
 
     def train_step(self, batch):
         img_batch, lb_batch = self.preprocess_batch(batch)
+        if self.graphed_step is not None:
+            # zero_grad + forward + loss + backward + step as ONE hipGraph launch
+            return dict(ce_loss=self.graphed_step(img_batch, lb_batch))
         micro = getattr(self, "micro_step", 0)
         first = micro % self.grad_accum_steps == 0
         sync = self.should_sync(micro)

@@ -35,6 +35,7 @@ def parse_args(argv=None):
     ap.add_argument("--num-workers", type=int, default=0)
     ap.add_argument("--steps", type=int, default=None, help="cap on steps per epoch (smoke runs)")
     ap.add_argument("--no-progress", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (1 process)")
     return ap.parse_args(argv)
 
 
@@ -67,7 +68,7 @@ if __name__ == "__main__":
                              grad_accum_steps=args.grad_accum,
                              num_workers=args.num_workers,
                              max_steps_per_epoch=args.steps,
-                             progress=not args.no_progress,
+                             progress=not args.no_progress, use_hip_graph=args.hip_graph,
                              metrics_file="%s/metrics.jsonl" % args.save_folder)
 
     trainer.train()

@@ -264,3 +264,62 @@ def test_fused_bias_grads_match_standalone_colsum():
         else:
             ref = plain[s].abs().max().item()
             assert (fused[s] - plain[s]).abs().max().item() <= 1e-4 * ref + 1e-7, n
+
+
+def test_hip_graph_step_matches_eager_and_redraws_dropout():
+    """GraphedTrainStep: (a) with dropout off, N graph replays == N eager steps bit for bit;
+    (b) with dropout on, replays draw different masks (device-resident seed) and still train;
+    (c) an LR change re-captures."""
+    from distributed_training_pytorch_amd.engine.graph import GraphedTrainStep
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    torch.manual_seed(21)
+    xs = [torch.randn(4, 3, 32, 32, device="cuda") for _ in range(6)]
+    ys = [torch.randint(0, 3, (4,), device="cuda") for _ in range(6)]
+
+    def make(dropout):
+        torch.manual_seed(22)
+        m = VGG16(3, 3, True, dropout=dropout).to("cuda").train()
+        return m, FusedSGD(m, lr=0.002, momentum=0.9, weight_decay=1e-4), SoftmaxCrossEntropy()
+
+    m1, o1, c1 = make(0.0)
+    m2, o2, c2 = make(0.0)
+    g = GraphedTrainStep(m2, c2, o2, warmup=2)
+    assert g.enabled
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        o1.zero_grad()
+        l1 = c1(m1(x), y)
+        l1.backward()
+        o1.step()
+        l2 = g(x, y)
+        assert torch.equal(l1.detach(), l2), "step %d: eager %r graph %r" % (i, float(l1), float(l2))
+    torch.cuda.synchronize()
+    assert g.captures == 1 and g.replays == 4
+    assert torch.equal(m1.param_arena.flat_master, m2.param_arena.flat_master)
+    assert o2._steps == o1._steps == 6
+    for grp in o2.param_groups:                       # MultiStepLR milestone
+        grp["lr"] = 0.001
+    for grp in o1.param_groups:
+        grp["lr"] = 0.001
+    for x, y in zip(xs[:4], ys[:4]):
+        o1.zero_grad()
+        c1(m1(x), y).backward()
+        o1.step()
+        g(x, y)
+    torch.cuda.synchronize()
+    assert g.captures == 2
+    assert torch.equal(m1.param_arena.flat_master, m2.param_arena.flat_master)
+    # eval after graph steps sees the updated weights
+    m1.eval(); m2.eval()
+    with torch.no_grad():
+        assert torch.equal(m1(xs[0]), m2(xs[0]))
+
+    m3, o3, c3 = make(0.3)
+    for grp in o3.param_groups:                       # frozen weights: only the masks can move the loss
+        grp["lr"], grp["weight_decay"] = 0.0, 0.0
+    g3 = GraphedTrainStep(m3, c3, o3, warmup=1)
+    losses = [float(g3(xs[0], ys[0])) for _ in range(8)]
+    assert g3.captures == 1 and g3.replays == 7
+    assert all(l == l for l in losses)
+    assert len(set(losses[1:])) >= 6                  # every replay drew a fresh dropout mask
