@@ -26,7 +26,7 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
 _SIGS = {
     "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_float, c_ull, c_void_p, c_int, c_int, c_void_p],
+                     c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],
@@ -37,6 +37,7 @@ _SIGS = {
     "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_maxpool2x2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                            ctypes.POINTER(c_int), c_void_p],
+    "dtp_quant_fp8": [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     "dtp_colsum_parts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "dtp_avgpool_flatten_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_avgpool_flatten_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -273,3 +273,80 @@ extern "C" int dtp_relu_mask(const void* g, const void* y, void* out, size_t n, 
                      (bf16_t*)out, n, scale);
   return DTP_CHECK_LAUNCH();
 }
+
+// ------------------------------------------------------------------------------------ fp8 (OCP e4m3) quantisation
+// Per-tensor scaling for the fp8 classifier GEMMs (BASELINE.json config 5): amax -> scale = amax/448
+// -> q = e4m3(x / scale).  Two-pass deterministic amax (no float atomics); everything stays on the
+// device (the GEMM reads the dequantisation factors from memory), so no host sync.
+template <typename T>
+DTP_DEVINL float abs_as_f32(const T* p);
+template <> DTP_DEVINL float abs_as_f32<float>(const float* p) { return fabsf(*p); }
+template <> DTP_DEVINL float abs_as_f32<bf16_t>(const bf16_t* p) { return fabsf(bf16_to_f32(*p)); }
+
+template <typename T>
+__global__ void amax_pass1_kernel(const T* __restrict__ x, size_t n, float* __restrict__ part) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, abs_as_f32<T>(x + i));
+  __shared__ float red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// scale_out[0] = dequantisation factor (amax / 448, or 1 for an all-zero tensor)
+__global__ void amax_pass2_kernel(const float* __restrict__ part, int nb, float* __restrict__ scale_out) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, part[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale_out[0] = red[0] > 0.f ? red[0] * (1.f / 448.f) : 1.f;
+}
+
+template <typename T>
+__global__ void quant_fp8_kernel(const T* __restrict__ x, size_t n4, const float* __restrict__ scale,
+                                 uint32_t* __restrict__ out) {
+  const float inv = 1.f / scale[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float f = load_as_f32<T>(x + 4 * i + e) * inv;
+      v[e] = fminf(fmaxf(f, -448.f), 448.f);
+    }
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    out[i] = (uint32_t)w;
+  }
+}
+
+// x: n elements of f32 (kind 0) or bf16 (kind 1), n % 4 == 0 -> out: n bytes of e4m3; scale_out[0] = dequant factor;
+// workspace: >= 1024 floats
+extern "C" int dtp_quant_fp8(const void* x, int kind, size_t n, void* out, float* scale_out, float* workspace,
+                             hipStream_t s) {
+  if (n == 0 || (n & 3) || (kind != 0 && kind != 1)) return -10;
+  int nb = (int)((n + 256 * 16 - 1) / (256 * 16));
+  if (nb > 1024) nb = 1024;
+  const int qb = grid_for(n / 4, 256, 4096);
+  if (kind == 0) {
+    hipLaunchKernelGGL(amax_pass1_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, n, workspace);
+    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out);
+    hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(qb), dim3(256), 0, s, (const float*)x, n / 4, scale_out,
+                       (uint32_t*)out);
+  } else {
+    hipLaunchKernelGGL(amax_pass1_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, n, workspace);
+    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out);
+    hipLaunchKernelGGL(quant_fp8_kernel<bf16_t>, dim3(qb), dim3(256), 0, s, (const bf16_t*)x, n / 4, scale_out,
+                       (uint32_t*)out);
+  }
+  return DTP_CHECK_LAUNCH();
+}

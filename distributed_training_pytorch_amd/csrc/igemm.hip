@@ -42,14 +42,33 @@ struct IgemmParams {
   float mask_scale;
   float drop_p;
   unsigned long long seed;
+  const float* dq_a;                    // optional device scalars: accumulator *= *dq_a * *dq_b (fp8 dequant)
+  const float* dq_b;
   const unsigned long long* seed_ptr;   // optional device-resident base seed (hipGraph replay): seed += *seed_ptr
   int ksteps_total;
   int ksteps_per_split;
   int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE>
+// 16x16x32 MFMA step on one 16-byte fragment pair.  FP8: the 16 bytes are 16 OCP e4m3 values, fed
+// to two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each); A and B use the same lane->k map, so
+// the k order inside the 128-element chunk is irrelevant to the dot product.
+template <bool FP8>
+DTP_DEVINL f32x4_t mma16(const bf16x8_t& w, const bf16x8_t& x, f32x4_t c) {
+  if constexpr (FP8) {
+    typedef long l2_t __attribute__((ext_vector_type(2)));
+    const l2_t wl = __builtin_bit_cast(l2_t, w), xl = __builtin_bit_cast(l2_t, x);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], xl[0], c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], xl[1], c, 0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmParams p) {
+  static_assert(!FP8 || (PIPE == 0 && !TAPS9), "fp8 operands: plain GEMM, 2-stage loop only");
+  constexpr int ES = FP8 ? 1 : 2;     // operand element size; a K-step is always 128 bytes per row
   constexpr int T = WGM * WGN * 64;
   constexpr int RP = T / 8;          // tile rows covered by one staging pass (8 lanes per 128-B row)
   constexpr int AP = BM / RP;
@@ -102,7 +121,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       aptr[i] = p.A + ((size_t)m * p.C + lch * 8) * 2;
     } else {
       amask[i] = inb ? 1u : 0u;
-      aptr[i] = p.A + ((size_t)m * p.lda + lch * 8) * 2;
+      aptr[i] = p.A + (size_t)m * p.lda * ES + lch * 16;
     }
   }
   const char* bptr[BP];
@@ -111,7 +130,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   for (int i = 0; i < BP; ++i) {
     const int n = n0 + srow + i * RP;
     bok[i] = n < p.Ncols;
-    bptr[i] = p.B + ((size_t)n * p.ldb + lch * 8) * 2;
+    bptr[i] = p.B + (size_t)n * p.ldb * ES + lch * 16;
   }
   const int cchunks = p.C >> 6;   // 64-channel chunks per tap
 
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma16<FP8>(wf[j], xf[i], acc[i][j]);
     }
   };
 
@@ -417,6 +436,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   }
 
   // ---------------- epilogue
+  if (p.dq_a) {                        // kernel-uniform: fp8 dequantisation of the accumulators
+    const float dq = p.dq_a[0] * p.dq_b[0];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) acc[i][j] *= dq;
+  }
   const int prow = lane & 15;          // pixel within a 16-block
   const int cq = (lane >> 4) * 4;      // first of 4 consecutive channels within a 16-block
   if (gridDim.y > 1 || p.out_fp32) {
@@ -564,14 +590,14 @@ __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ partial, in
 }
 
 // -------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false>
 static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Ncols + BN - 1) / BN;
   constexpr int lds = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE>;
+  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE, FP8>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -2;
@@ -586,9 +612,11 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             float* partial, float* colsum_part, const void* zero_page, int M, int Ncols, int C,
                             int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
-                            float drop_p, unsigned long long seed, const void* seed_ptr, int nsplit, int cfg,
-                            hipStream_t stream) {
-  if (M <= 0 || Ncols <= 0 || C <= 0 || (C & 63)) return -10;          // K chunks are 64 wide
+                            float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
+                            const float* dq_a, const float* dq_b, int nsplit, int cfg, hipStream_t stream) {
+  // fp8 (OCP e4m3) operands: A [M][lda], B [Ncols][ldb] bytes, K = C a multiple of 128
+  if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
+  if (fp8 && (taps != 1 || (lda & 15) || (ldb & 15))) return -18;
   if (taps != 1 && taps != 9) return -11;
   if (taps == 9 && (H <= 0 || W <= 0 || M % (H * W) != 0)) return -12;
   if (!out_fp32 && ((Ncols & 7) || (ldo & 7))) return -13;               // 16-byte bf16 row chunks
@@ -600,7 +628,9 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
   p.seed_ptr = (const unsigned long long*)seed_ptr;
-  p.ksteps_total = taps * (C >> 6);
+  p.dq_a = dq_a; p.dq_b = dq_b;
+  if (fp8 && (!dq_a || !dq_b)) return -19;
+  p.ksteps_total = taps * (C >> (fp8 ? 7 : 6));
   if (nsplit < 1) nsplit = 1;
   if (nsplit > p.ksteps_total) nsplit = p.ksteps_total;
   p.ksteps_per_split = (p.ksteps_total + nsplit - 1) / nsplit;
@@ -612,6 +642,14 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
 #define DTP_IG(BM_, BN_, WGM_, WGN_, PIPE_)                                     \
   (t9 ? launch_cfg<BM_, BN_, WGM_, WGN_, true, PIPE_>(p, nsplit, stream)        \
       : launch_cfg<BM_, BN_, WGM_, WGN_, false, PIPE_>(p, nsplit, stream))
+  if (fp8) {
+    switch (cfg) {
+      case 1: rc = launch_cfg<256, 128, 4, 2, false, 0, true>(p, nsplit, stream); break;
+      case 3: rc = launch_cfg<128, 128, 2, 2, false, 0, true>(p, nsplit, stream); break;
+      case 4: rc = launch_cfg<128, 64, 2, 1, false, 0, true>(p, nsplit, stream); break;
+      default: return -16;
+    }
+  } else
   switch (cfg) {   // cfg 0-4: plain 2-stage loop; 8-12: software-pipelined K-step
     case 0: rc = DTP_IG(256, 256, 2, 4, 0); break;
     case 1: rc = DTP_IG(256, 128, 4, 2, 0); break;

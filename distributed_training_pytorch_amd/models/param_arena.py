@@ -127,19 +127,32 @@ class ParamArena(object):
                 self.flat_grad[self.offsets[i]:self.offsets[i] + p.numel()].zero_()
 
     def sync_autograd_grad(self, p):
-        """Bring an autograd-produced ``p.grad`` (fresh tensor or other dtype) into the arena."""
+        """Bring an autograd-produced ``p.grad`` (fresh tensor or other dtype: BatchNorm affine
+        parameters, generic fallbacks) into the arena: overwrite on the first write after
+        zero_grad, accumulate afterwards (gradient accumulation)."""
         if id(p) in self.kernel_written or p.grad is None:
             return
         i = self.index[id(p)]
         view = self._logical_view(self.flat_grad, i)
         if p.grad.data_ptr() == view.data_ptr():
+            self.fresh[i] = False
             return
         with torch.no_grad():
-            view.copy_(p.grad)
-            if self.grad_dtype == p.dtype:
-                p.grad = view
+            if self.fresh[i]:
+                view.copy_(p.grad)
             else:
-                p.grad = None
+                view.add_(p.grad.to(view.dtype))
+            self.fresh[i] = False
+            p.grad = view if self.grad_dtype == p.dtype else None
+
+    def collect_autograd_grads(self):
+        """GPU optimizer path: parameters whose gradients come from torch.autograd rather than
+        from the fused kernels (none in plain VGG16; the BatchNorm affine pairs of VGG16-BN)."""
+        if len(self.kernel_written) == len(self.params):
+            return
+        for p in self.params:
+            if id(p) not in self.kernel_written:
+                self.sync_autograd_grad(p)
 
     def grad_beta(self, p):
         """0.0 on the first gradient write after zero_grad (overwrite), 1.0 afterwards."""

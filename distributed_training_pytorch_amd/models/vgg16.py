@@ -61,8 +61,9 @@ class ConvBlock(nn.Module):
 
 class VGG16(nn.Module):
     def __init__(self, in_channels=3, out_channels=1, init_weights=True, batch_norm=False,
-                 dropout=0.3, grad_dtype=torch.float32):
+                 dropout=0.3, grad_dtype=torch.float32, fp8_classifier=False):
         super().__init__()
+        self.fp8_classifier = bool(fp8_classifier)   # linear1/linear2 forward GEMMs in OCP e4m3
         self.batch_norm = batch_norm
         self.grad_dtype = grad_dtype
         self.backbone = nn.Sequential(ConvBlock(in_channels, 64, first=True, batch_norm=batch_norm),
@@ -71,9 +72,10 @@ class VGG16(nn.Module):
                                       ConvBlock(256, 512, num_layers=3, batch_norm=batch_norm),
                                       ConvBlock(512, 512, num_layers=3, batch_norm=batch_norm))
         self.avgpool = AvgPoolFlatten((7, 7))
-        self.linear1 = Linear(512 * 7 * 7, 4096, relu=True, drop_p=dropout, grad_premasked=True)
+        self.linear1 = Linear(512 * 7 * 7, 4096, relu=True, drop_p=dropout, grad_premasked=True,
+                              fp8=fp8_classifier)
         self.linear2 = Linear(4096, 4096, relu=True, drop_p=dropout, input_is_relu_out=True,
-                              input_drop_p=dropout, grad_premasked=True)
+                              input_drop_p=dropout, grad_premasked=True, fp8=fp8_classifier)
         # kept for attribute parity with the reference (model/vgg16.py:39-40); fused on the GPU
         self.relu = ReLUMarker()
         self.dropout = nn.Dropout(dropout)

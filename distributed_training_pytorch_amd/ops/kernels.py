@@ -163,9 +163,16 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
-           mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None):
-    ksteps = taps * (C // 64)
+           mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None):
+    fp8 = fp8_scales is not None
+    ksteps = taps * (C // (128 if fp8 else 64))
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
+    if fp8:      # fp8 operands are instantiated for the 2-stage 256x128 / 128x128 / 128x64 tiles
+        cfg = {16: 1, 0: 1, 8: 1, 9: 1, 1: 1, 11: 3, 3: 3, 2: 4, 10: 4, 12: 4, 4: 4}[cfg]
+        if IGEMM_TILES[cfg][0] * IGEMM_TILES[cfg][1] < 256 * 256 and nsplit == 1:
+            tiles = _cdiv(M, IGEMM_TILES[cfg][0]) * _cdiv(Ncols, IGEMM_TILES[cfg][1])
+            if tiles < N_CU and ksteps >= 16:
+                nsplit = max(1, min(ksteps // 8, _cdiv(2 * N_CU, tiles)))
     partial = None
     if nsplit > 1:
         partial = workspace.get("igemm_partial", nsplit * M * Ncols, torch.float32, A.device)
@@ -177,7 +184,8 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial), ptr(cs_part),
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
-                                 ptr(seed_ptr), nsplit, cfg, stream())
+                                 ptr(seed_ptr), int(fp8), ptr(fp8_scales[0]) if fp8 else None,
+                                 ptr(fp8_scales[1]) if fp8 else None, nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
@@ -253,6 +261,38 @@ def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, 
         raise ValueError("seed_ptr must be a CUDA int64 tensor")
     return _igemm(x, w, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed,
                   seed_ptr=seed_ptr)
+
+
+def quant_fp8(x):
+    """Per-tensor OCP e4m3 quantisation on the device: returns (q uint8 tensor shaped like x,
+    scale f32[1]) with x ~= q * scale; amax, scale and conversion never touch the host."""
+    if not x.is_cuda or not x.is_contiguous() or x.dtype not in (torch.float32, BF16) or x.numel() % 4:
+        raise ValueError("quant_fp8: contiguous CUDA f32/bf16 tensor with numel % 4 == 0")
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = workspace.get("amax", 1024, torch.float32, x.device)
+    check(_lib.hip().dtp_quant_fp8(ptr(x), int(x.dtype == BF16), x.numel(), ptr(q), ptr(scale), ptr(ws), stream()),
+          "quant_fp8")
+    return q, scale
+
+
+def linear_fwd_fp8(xq, x_scale, wq, w_scale, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False,
+                   seed_ptr=None):
+    """y = (xq @ wq.T) * x_scale * w_scale (+bias)(relu)(dropout) on v_mfma_f32_16x16x32_fp8_fp8;
+    xq [M,K] / wq [Nout,K] uint8 holding e4m3, K % 128 == 0, f32 accumulation."""
+    for t, name in ((xq, "xq"), (wq, "wq")):
+        _need(t, torch.uint8, name)
+    M, K = xq.shape
+    Nout = wq.shape[0]
+    if wq.shape[1] != K or K % 128:
+        raise ValueError("linear_fwd_fp8: bad shapes xq=%s wq=%s" % (tuple(xq.shape), tuple(wq.shape)))
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    if not out_fp32 and Nout % 8:
+        raise ValueError("bf16 output needs out_features % 8 == 0 (use out_fp32)")
+    out = torch.empty((M, Nout), dtype=torch.float32 if out_fp32 else BF16, device=xq.device)
+    return _igemm(xq, wq, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed,
+                  seed_ptr=seed_ptr, fp8_scales=(x_scale, w_scale))
 
 
 def linear_dgrad(dy, wt, ld_dy=None, mask_src=None, mask_scale=1.0, out=None):

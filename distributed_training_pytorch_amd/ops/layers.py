@@ -268,8 +268,17 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer, drop_p, seed, seed_ptr=None):
         arena = _arena_of(layer)
-        y = K.linear_fwd(x, arena.lp(weight), bias.detach(), relu=layer.relu, drop_p=drop_p, seed=seed,
-                         out_fp32=layer.out_fp32, seed_ptr=seed_ptr)
+        if layer.fp8 and x.shape[1] % 128 == 0:
+            # fp8 (OCP e4m3) forward GEMM, per-tensor scales computed on the device; the weight copy
+            # is re-quantised once per optimizer step (cache keyed on the arena's lp epoch);
+            # backward stays on the bf16 operands
+            wq, w_scale = layer._cached("w_fp8", lambda: K.quant_fp8(arena.lp(weight)))
+            xq, x_scale = K.quant_fp8(x)
+            y = K.linear_fwd_fp8(xq, x_scale, wq, w_scale, bias.detach(), relu=layer.relu, drop_p=drop_p,
+                                 seed=seed, out_fp32=layer.out_fp32, seed_ptr=seed_ptr)
+        else:
+            y = K.linear_fwd(x, arena.lp(weight), bias.detach(), relu=layer.relu, drop_p=drop_p, seed=seed,
+                             out_fp32=layer.out_fp32, seed_ptr=seed_ptr)
         ctx.layer = layer
         ctx.in_scale = layer._input_mask_scale()
         ctx.save_for_backward(x, y, weight, bias)
@@ -306,8 +315,9 @@ class Linear(FusedLayer):
     reference model/vgg16.py:71-76).  ``out_fp32`` for the logits layer."""
 
     def __init__(self, in_features, out_features, relu=False, drop_p=0.0, out_fp32=False,
-                 input_is_relu_out=False, input_drop_p=0.0, grad_premasked=False):
+                 input_is_relu_out=False, input_drop_p=0.0, grad_premasked=False, fp8=False):
         super().__init__()
+        self.fp8 = bool(fp8)        # forward GEMM on fp8 MFMA (GPU only; CPU path ignores it)
         self.in_features, self.out_features = in_features, out_features
         self.relu, self.drop_p, self.out_fp32 = relu, float(drop_p), out_fp32
         self.input_is_relu_out = input_is_relu_out

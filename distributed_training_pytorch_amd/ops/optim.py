@@ -105,6 +105,7 @@ class FusedSGD(_FusedBase):
         first = self._steps == 0
         mom = self._flat_state["momentum_buffer"]
         if a.flat_master.is_cuda:
+            a.collect_autograd_grads()
             K.sgd_flat(a.flat_master, a.flat_grad, mom, a.flat_lp, g["lr"], g["momentum"], g["dampening"],
                        g["weight_decay"], grad_scale, g["nesterov"], first)
             a.lp_written_by_optimizer()
@@ -138,6 +139,7 @@ class FusedAdamW(_FusedBase):
         m, v = self._flat_state["exp_avg"], self._flat_state["exp_avg_sq"]
         self._steps += 1
         if a.flat_master.is_cuda:
+            a.collect_autograd_grads()
             K.adamw_flat(a.flat_master, a.flat_grad, m, v, a.flat_lp, g["lr"], b1, b2, g["eps"],
                          g["weight_decay"], grad_scale, self._steps)
             a.lp_written_by_optimizer()

@@ -53,6 +53,7 @@ class ExampleTrainer(Trainer):
                  milestones=(50, 100, 200),
                  batch_norm=False,
                  grad_dtype=torch.float32,
+                 fp8_classifier=False,
                  **engine_kwargs):
         self.train_path = train_path
         self.val_path = val_path
@@ -63,6 +64,7 @@ class ExampleTrainer(Trainer):
         self.milestones = list(milestones)
         self.batch_norm = batch_norm
         self.grad_dtype = grad_dtype
+        self.fp8_classifier = fp8_classifier
         super().__init__(max_epoch, batch_size, pin_memory, have_validate, save_best_for, save_period,
                          save_folder, snapshot_path, logger, **engine_kwargs)
 
@@ -81,7 +83,8 @@ class ExampleTrainer(Trainer):
 
     # model / loss / optimiser -----------------------------------------------------------------
     def build_model(self):
-        return VGG16(3, len(self.labels), True, batch_norm=self.batch_norm, grad_dtype=self.grad_dtype)
+        return VGG16(3, len(self.labels), True, batch_norm=self.batch_norm, grad_dtype=self.grad_dtype,
+                     fp8_classifier=self.fp8_classifier)
 
     def build_criterion(self):
         return SoftmaxCrossEntropy()

@@ -51,12 +51,13 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--device", default=DEVICE)
     ap.add_argument("--batch-norm", action="store_true")
+    ap.add_argument("--fp8-classifier", action="store_true")
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic test samples")
     args = ap.parse_args(argv)
     labels = args.labels.split(",")
     device = torch.device(args.device)
 
-    model = VGG16(3, len(labels), True, batch_norm=args.batch_norm)
+    model = VGG16(3, len(labels), True, batch_norm=args.batch_norm, fp8_classifier=args.fp8_classifier)
     ckpt = load_snapshot(args.model)
     model.load_state_dict(ckpt["model_state_dict"])
     model = model.to(device)

@@ -30,6 +30,7 @@ def parse_args(argv=None):
     ap.add_argument("--snapshot", default=None, help="resume from this snapshot (e.g. runs/weights/last.pth)")
     ap.add_argument("--no-validate", action="store_true")
     ap.add_argument("--batch-norm", action="store_true", help="VGG16-BN variant")
+    ap.add_argument("--fp8-classifier", action="store_true", help="linear1/linear2 forward GEMMs in OCP e4m3 (GPU)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--grad-accum", type=int, default=1)
     ap.add_argument("--num-workers", type=int, default=0)
@@ -63,7 +64,7 @@ if __name__ == "__main__":
                              snapshot_path=args.snapshot,
                              logger=logger,
                              lr=args.lr,
-                             batch_norm=args.batch_norm,
+                             batch_norm=args.batch_norm, fp8_classifier=args.fp8_classifier,
                              grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32,
                              grad_accum_steps=args.grad_accum,
                              num_workers=args.num_workers,

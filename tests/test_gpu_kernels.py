@@ -455,3 +455,32 @@ def test_fused_bias_grad_from_maxpool_backward(shape):
         k.fuse_colsum = True
     assert torch.equal(dx, dx2)
     _close(out, out2, 1e-5, 1e-3, "pool colsum vs stand-alone %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 1024), (200, 4096, 25088 // 4), (256, 64, 128), (8, 4096, 4096)])
+def test_fp8_quant_and_linear_forward(shape):
+    """fp8 (OCP e4m3) classifier GEMM: device-side per-tensor quantisation matches torch's
+    float8_e4m3fn cast, and the MFMA GEMM matches an fp32 matmul of the dequantised operands."""
+    k = _k()
+    M, N, K = shape
+    torch.manual_seed(13)
+    x = _rand(M, K).relu()                         # classifier inputs are ReLU outputs
+    w = (torch.randn(N, K, device="cuda") * 0.02).to(BF16)
+    b = torch.randn(N, device="cuda")
+    xq, xs = k.quant_fp8(x)
+    wq, ws = k.quant_fp8(w)
+    assert abs(xs.item() - x.float().abs().max().item() / 448.0) < 1e-6 * xs.item() + 1e-12
+    ref_xq = (x.float() / xs).to(torch.float8_e4m3fn)
+    same = (xq.view(torch.float8_e4m3fn).float() == ref_xq.float()).float().mean().item()
+    assert same > 0.999, "quantisation differs from torch's e4m3fn cast on %.4f%% of elements" % (100 * (1 - same))
+    xd = xq.view(torch.float8_e4m3fn).float() * xs
+    wd = wq.view(torch.float8_e4m3fn).float() * ws
+    ref = torch.relu(xd @ wd.t() + b)
+    y = k.linear_fwd_fp8(xq, xs, wq, ws, b, relu=True)
+    _close(y, ref, 1e-2, 1e-2 * ref.abs().max().item(), "fp8 linear %s" % (shape,))
+    y32 = k.linear_fwd_fp8(xq, xs, wq, ws, b, relu=True, out_fp32=True)
+    _close(y32, ref, 2e-3, 2e-3 * ref.abs().max().item(), "fp8 linear f32 out %s" % (shape,))
+    # and the quantisation error against the bf16 GEMM is the expected few percent
+    full = torch.relu(x.float() @ w.float().t() + b)
+    rel = (y32 - full).norm().item() / (full.norm().item() + 1e-12)
+    assert rel < 0.06, rel
