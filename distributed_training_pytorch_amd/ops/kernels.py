@@ -19,7 +19,7 @@ N_CU = 256
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256),
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
-WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64)}
+WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 256)}
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
 

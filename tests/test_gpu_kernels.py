@@ -135,7 +135,7 @@ def test_conv3x3_wgrad(shape, out_dtype):
     _close(out, 2 * ref, 3e-2, 3e-2 * scale, "wgrad-acc%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_conv3x3_wgrad_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(4)
@@ -146,7 +146,7 @@ def test_conv3x3_wgrad_all_tile_configs(cfg):
     wref = torch.zeros(Co, C, 3, 3, device="cuda", requires_grad=True)
     (gw,) = torch.autograd.grad(F.conv2d(xr, wref, padding=1), wref, dy.float().permute(0, 3, 1, 2))
     ref = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
-    for nsplit in (1, 4):
+    for nsplit in (1, 4, 3):          # 7 K-tiles: odd counts per split exercise the 8-phase zero tile
         k._overrides["wgrad"] = lambda M, Cc, taps, ks: (cfg, nsplit)
         try:
             out = torch.empty((Co, 9 * C), device="cuda")
@@ -484,3 +484,38 @@ def test_fp8_quant_and_linear_forward(shape):
     full = torch.relu(x.float() @ w.float().t() + b)
     rel = (y32 - full).norm().item() / (full.norm().item() + 1e-12)
     assert rel < 0.06, rel
+
+
+@pytest.mark.parametrize("shape", [(2, 28, 28, 512, 512), (3, 7, 9, 256, 512), (1, 56, 56, 256, 256)])
+def test_wgrad_8phase_schedule(shape):
+    """cfg 5 (8-phase counted-vmcnt 256x256 weight-gradient kernel) on conv shapes incl. K tails,
+    bf16 output with beta accumulation, and the linear (taps == 1) form with M / N tails."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(14)
+    x = _rand(N, H, W, C)
+    dy = _rand(N, H, W, Co, scale=0.1)
+    xr = x.float().permute(0, 3, 1, 2)
+    wref = torch.zeros(Co, C, 3, 3, device="cuda", requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv2d(xr, wref, padding=1), wref, dy.float().permute(0, 3, 1, 2))
+    ref = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    for nsplit, dt, beta in ((1, torch.float32, 0.0), (5, torch.float32, 1.0), (2, BF16, 1.0)):
+        k._overrides["wgrad"] = lambda M, Cc, taps, ks: (5, nsplit)
+        try:
+            out = torch.full((Co, 9 * C), 0.5, device="cuda", dtype=dt)
+            k.conv3x3_wgrad(dy, x, out, beta=beta)
+        finally:
+            k._overrides.pop("wgrad")
+        _close(out, ref + 0.5 * beta, 2e-2, 2e-2 * ref.abs().max().item(), "wgrad8 %s split%d" % (shape, nsplit))
+    # linear form: dW[Nout, K] = dy^T x with tails in every dimension
+    M, Kin, Nout = 200, 520, 300
+    xl = _rand(M, Kin)
+    dl = _rand(M, 320, scale=0.1)
+    k._overrides["wgrad"] = lambda Mm, Cc, taps, ks: (5, 2)
+    try:
+        gl = torch.empty((Nout, Kin), device="cuda")
+        k.linear_wgrad(dl, xl, gl, n_valid=Nout)
+    finally:
+        k._overrides.pop("wgrad")
+    refl = dl.float()[:, :Nout].t() @ xl.float()
+    _close(gl, refl, 2e-2, 2e-2 * refl.abs().max().item(), "wgrad8 linear")
