@@ -84,11 +84,13 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
+    exposed0 = dp.reducer.exposed_ms_total()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    exposed = (dp.reducer.exposed_ms_total() - exposed0) / max(1, args.steps)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -106,6 +108,7 @@ def main():
                         "the reference publishes no numbers" % STOCK_1GPU_BF16_IMG_S,
             "dtype": "bf16", "data": "synthetic (device-resident f32 NCHW batches, random-init weights)",
             "final_loss": final_loss,
+            "allreduce_exposed_ms_per_step": exposed,     # compute stream idle waiting for gradient buckets (rank 0)
             "config": {"model": "VGG16 (no BN, %d classes, 134M params)" % args.classes,
                        "global_batch": global_batch, "image_size": args.image_size,
                        "seq_len": None, "parallelism": "dp%d" % world,

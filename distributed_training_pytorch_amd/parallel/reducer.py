@@ -139,6 +139,11 @@ class BucketedReducer(object):
         self._hooks = []
         self._ready_ids = set()      # params already counted in this backward pass
         self.stats = dict(launched=0, finalized=0, bytes=0)
+        # exposed communication: HIP-event pairs around the waits of _finalize (compute stream idle
+        # until the last buckets land); read lazily, never a host sync on the hot path
+        self._exposed_pairs = []
+        self._exposed_ms = 0.0
+        self.measure_exposed = on_gpu
 
         gdtype = grad_dtype or (flat_grad.dtype if flat_grad is not None else self.params[0].dtype)
         elem = torch.empty((), dtype=gdtype).element_size()
@@ -261,6 +266,10 @@ class BucketedReducer(object):
             for b in self.buckets:      # parameters that produced no gradient this pass
                 if not b.launched:
                     self._launch(b)
+            ev0 = ev1 = None
+            if self.measure_exposed and self.world > 1:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for b in self.buckets:
                 buf = b.comm_buf if b.comm_buf is not None else b.flat
                 self.transport.wait(b.work, buf)
@@ -269,6 +278,9 @@ class BucketedReducer(object):
                     b.comm_buf = None
                 if self._owns_grads:
                     self._scatter_split_params(b)
+            if ev0 is not None:
+                ev1.record()
+                self._exposed_pairs.append((ev0, ev1))
             self.stats["finalized"] += 1
         self._ready_ids.clear()
         for b in self.buckets:
@@ -287,6 +299,18 @@ class BucketedReducer(object):
             if whole and g.data_ptr() == src.data_ptr():
                 continue
             g.reshape(-1)[s:e].copy_(src)
+
+    def exposed_ms_total(self):
+        """Milliseconds the compute stream has spent waiting for gradient buckets so far (pairs
+        whose events have completed; the rest is picked up by a later call)."""
+        keep = []
+        for e0, e1 in self._exposed_pairs:
+            if e1.query():
+                self._exposed_ms += e0.elapsed_time(e1)
+            else:
+                keep.append((e0, e1))
+        self._exposed_pairs = keep
+        return self._exposed_ms
 
     def finalize_now(self):
         """Explicit finalize for engines that do not run through ``torch.autograd``."""

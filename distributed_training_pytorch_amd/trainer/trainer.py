@@ -25,6 +25,8 @@ import os
 import time
 
 import torch
+
+from ..utils.profiler import trace_range
 from torch.utils.data import DataLoader
 
 from ..data.prefetch import DevicePrefetcher
@@ -266,12 +268,26 @@ class Trainer(object):
             sums, count = None, 0
             self.meter.start()
             loop = self._progress(DevicePrefetcher(self.train_dataloader, self.device))
-            for i, batch in enumerate(loop):
+            it, i = iter(loop), -1
+            data_wait_s = step_host_s = 0.0
+            reducer = getattr(self.model, "reducer", None)
+            exposed0 = reducer.exposed_ms_total() if reducer is not None else 0.0
+            while True:
+                t0 = time.perf_counter()
+                with trace_range("data_wait"):
+                    batch = next(it, None)
+                if batch is None:
+                    break
+                i += 1
                 if self.max_steps_per_epoch is not None and i >= self.max_steps_per_epoch:
                     break
+                t1 = time.perf_counter()
+                data_wait_s += t1 - t0
                 self._maybe_inject_fault()
                 self.micro_step = i
-                loss = self.train_step(batch)
+                with trace_range("train_step"):
+                    loss = self.train_step(batch)
+                step_host_s += time.perf_counter() - t1
                 n = self._batch_len(batch)
                 if sums is None:
                     sums = {k: (v.detach().float() if torch.is_tensor(v) else float(v)) * n for k, v in loss.items()}
@@ -283,6 +299,7 @@ class Trainer(object):
                 self.global_step += 1
                 if hasattr(loop, "set_postfix") and (i % self.log_every == 0):
                     loop.set_postfix({k: _to_float(v) for k, v in loss.items()})
+            steps_done = max(1, i + 1 if batch is None else i)
 
             # LR schedule (reference :159-160)
             if self.scheduler is not None:
@@ -312,7 +329,13 @@ class Trainer(object):
                         msg += " | %s = %s | " % (k, v)
                     self.log(msg)
                 self.log("THROUGHPUT: %.1f images/sec (%d images, %.2fs)" % (ips, self.meter.items, self.meter.elapsed))
-                self._write_metrics(dict(epoch=epoch + 1, images_per_sec=ips, **{"train_" + k: v for k, v in glob.items()}))
+                exposed = (reducer.exposed_ms_total() - exposed0) if reducer is not None else 0.0
+                self._write_metrics(dict(
+                    epoch=epoch + 1, images_per_sec=ips, steps=steps_done,
+                    data_wait_ms_per_step=1e3 * data_wait_s / steps_done,      # host blocked on the loader
+                    host_step_ms_per_step=1e3 * step_host_s / steps_done,      # host time inside train_step
+                    allreduce_exposed_ms_per_step=exposed / steps_done,        # GPU idle waiting for buckets
+                    **{"train_" + k: v for k, v in glob.items()}))
 
         self.log("Finished!")
 
