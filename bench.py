@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--grad-dtype", default=os.environ.get("DTP_BENCH_GRAD_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--grad-accum", type=int, default=1,
+                    help="micro-batches per optimizer step (BASELINE config 4): the per-GPU batch is split "
+                         "into this many micro-steps, all-reduce only on the last one (no_sync)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,14 +67,22 @@ def main():
     crit = SoftmaxCrossEntropy()
     dp = DataParallel(model)
     dp.train()
-    data = DeviceBatchSource(args.batch_per_gpu, args.classes, args.image_size, args.image_size,
+    if args.grad_accum < 1 or args.batch_per_gpu % args.grad_accum:
+        raise SystemExit("--batch-per-gpu must be a multiple of --grad-accum")
+    micro = args.batch_per_gpu // args.grad_accum
+    data = DeviceBatchSource(micro, args.classes, args.image_size, args.image_size,
                              device=dev, n_distinct=2, seed=rank)
 
     def step():
-        x, y = next(data)
         opt.zero_grad()
-        loss = crit(dp(x), y)
-        loss.backward()
+        for k in range(args.grad_accum):
+            x, y = next(data)
+            if k + 1 < args.grad_accum:
+                with dp.no_sync():
+                    (crit(dp(x), y) / args.grad_accum).backward()
+            else:
+                loss = crit(dp(x), y)
+                (loss / args.grad_accum if args.grad_accum > 1 else loss).backward()
         opt.step()
         return loss
 
@@ -113,7 +124,7 @@ def main():
                        "global_batch": global_batch, "image_size": args.image_size,
                        "seq_len": None, "parallelism": "dp%d" % world,
                        "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights",
-                       "grad_dtype": args.grad_dtype,
+                       "grad_dtype": args.grad_dtype, "grad_accum": args.grad_accum,
                        "grad_transport": type(dp.reducer.transport).__name__}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
