@@ -34,8 +34,8 @@ _SIGS = {
                      c_float, c_void_p],
     "dtp_wgrad_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
-    "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "dtp_maxpool2x2_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+    "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "dtp_maxpool2x2_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                            ctypes.POINTER(c_int), c_void_p],
     "dtp_quant_fp8": [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p],
     "dtp_colsum_parts": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],

@@ -376,29 +376,42 @@ def colsum(x2d, out, n_valid=None, beta=0.0):
     return out
 
 
-def maxpool2x2_fwd(x):
+def maxpool2x2_fwd(x, want_idx=False):
+    """y = maxpool 2x2/s2 of NHWC bf16 x.  ``want_idx``: also return the int32 tensor of 4-bit
+    (first-argmax, max > 0) codes that lets :func:`maxpool2x2_bwd` run without re-reading x."""
     _need(x, BF16, "x")
     N, H, W, C = x.shape
+    if C % 8 or H < 2 or W < 2:
+        raise ValueError("maxpool2x2_fwd: need C %% 8 == 0 and H, W >= 2, got %s" % (tuple(x.shape),))
     y = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=x.device)
-    check(_lib.hip().dtp_maxpool2x2_fwd(ptr(x), ptr(y), N, H, W, C, stream()), "maxpool_fwd")
-    return y
+    idx = torch.empty((N, H // 2, W // 2, C // 8), dtype=torch.int32, device=x.device) if want_idx else None
+    check(_lib.hip().dtp_maxpool2x2_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, C, stream()), "maxpool_fwd")
+    return (y, idx) if want_idx else y
 
 
-def maxpool2x2_bwd(x, dy, relu_mask=False):
-    _need(x, BF16, "x")
+def maxpool2x2_bwd(x, dy, relu_mask=False, idx=None, in_shape=None):
+    """dx of the 2x2 max-pool (first-max tie rule), optionally times (pool input > 0).  Either the
+    pool input ``x`` or the forward pass's ``idx`` codes (+ ``in_shape``) identify the winners."""
     _need(dy, BF16, "dy")
-    N, H, W, C = x.shape
+    if idx is None:
+        _need(x, BF16, "x")
+        N, H, W, C = x.shape
+    else:
+        N, H, W, C = in_shape
+        if idx.dtype != torch.int32 or not idx.is_contiguous() or tuple(idx.shape) != (N, H // 2, W // 2, C // 8):
+            raise ValueError("maxpool2x2_bwd: idx shape %s" % (tuple(idx.shape),))
+        x = None
     if tuple(dy.shape) != (N, H // 2, W // 2, C):
         raise ValueError("maxpool2x2_bwd: dy shape %s" % (tuple(dy.shape),))
-    dx = torch.empty_like(x)
+    dx = torch.empty((N, H, W, C), dtype=BF16, device=dy.device)
     cs_part, max_parts = None, 0
     if fuse_colsum and 256 % (C // 8) == 0 and H % 2 == 0 and W % 2 == 0:
         # dx is the dY of the convolution that produced x: leave its column sums behind
         max_parts = 1024
-        cs_part = workspace.get("colsum_parts", max_parts * C, torch.float32, x.device)
+        cs_part = workspace.get("colsum_parts", max_parts * C, torch.float32, dy.device)
     nparts = _ctypes.c_int(0)
-    check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask), ptr(cs_part),
-                                        max_parts, _ctypes.byref(nparts), stream()), "maxpool_bwd")
+    check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(idx), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask),
+                                        ptr(cs_part), max_parts, _ctypes.byref(nparts), stream()), "maxpool_bwd")
     if cs_part is not None and nparts.value > 0:
         colsum_slot.put(dx, cs_part, nparts.value, C)
     return dx

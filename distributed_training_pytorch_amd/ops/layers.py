@@ -211,15 +211,19 @@ class ConvFirst(FusedLayer):
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, relu_mask):
-        y = K.maxpool2x2_fwd(x)
+        # the forward pass leaves 4-bit (argmax, positive) codes: backward reads 1/16 of the bytes
+        # of the full-resolution input it would otherwise re-scan
+        y, idx = K.maxpool2x2_fwd(x, want_idx=True)
         ctx.relu_mask = relu_mask
-        ctx.save_for_backward(x)
+        ctx.in_shape = tuple(x.shape)
+        ctx.save_for_backward(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        return K.maxpool2x2_bwd(x, dy.contiguous(), relu_mask=ctx.relu_mask), None
+        (idx,) = ctx.saved_tensors
+        return K.maxpool2x2_bwd(None, dy.contiguous(), relu_mask=ctx.relu_mask, idx=idx,
+                                in_shape=ctx.in_shape), None
 
 
 class MaxPool2x2(nn.Module):

@@ -232,6 +232,12 @@ def test_maxpool(shape):
     assert torch.equal(dx.float(), gx.permute(0, 2, 3, 1))
     dxm = k.maxpool2x2_bwd(x, dy, relu_mask=True)
     assert torch.equal(dxm.float(), (gx * (xr > 0)).permute(0, 2, 3, 1))
+    # index-code path: the forward pass's 4-bit codes replace the input tensor in the backward pass
+    y2, idx = k.maxpool2x2_fwd(x, want_idx=True)
+    assert torch.equal(y2, y) and idx.dtype == torch.int32
+    for rm, ref in ((False, dx), (True, dxm)):
+        dxi = k.maxpool2x2_bwd(None, dy, relu_mask=rm, idx=idx, in_shape=tuple(x.shape))
+        assert torch.equal(dxi, ref)
 
 
 @pytest.mark.parametrize("hw", [(7, 7), (1, 1), (14, 14), (5, 3)])
