@@ -16,8 +16,10 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -126,6 +128,8 @@ def main():
                        "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights",
                        "grad_dtype": args.grad_dtype, "grad_accum": args.grad_accum,
                        "grad_transport": type(dp.reducer.transport).__name__}}), flush=True)
+    torch.cuda.synchronize()
+    dp.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -95,6 +95,14 @@ class DataParallel(nn.Module):
     def no_sync(self):
         return self.reducer.no_sync()
 
+    def close(self):
+        """Release the gradient transport (native RCCL communicator + stream); call before
+        ``destroy_process_group`` at the end of a run."""
+        self.reducer.remove_hooks()
+        tr = self.reducer.transport
+        if hasattr(tr, "close"):
+            tr.close()
+
     def state_dict(self, *args, **kwargs):
         return self.module.state_dict(*args, **kwargs)
 

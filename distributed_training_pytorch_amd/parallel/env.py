@@ -84,5 +84,10 @@ def ddp_setup(backend="nccl", timeout_s=None):
 
 
 def destroy_process():
+    try:     # native RCCL communicators go first, while the process group can still be used
+        from .rccl_native import _close_all
+        _close_all()
+    except Exception:
+        pass
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

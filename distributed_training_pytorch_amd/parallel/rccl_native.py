@@ -8,7 +8,9 @@ all collectives before the optimizer runs.  The RCCL unique id is created on ran
 through the already-initialised ``torch.distributed`` process group (any backend), which stays
 in charge of barriers / object broadcasts.
 """
+import atexit
 import ctypes
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -17,6 +19,17 @@ from .. import _lib
 from . import comm
 
 _KIND = {torch.float32: 0, torch.bfloat16: 1}
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    """Destroy communicators while the HIP runtime is still up (before interpreter teardown)."""
+    for t in list(_live):
+        try:
+            t.close()
+        except Exception:
+            pass
 
 
 def _rt():
@@ -64,6 +77,7 @@ class NativeRcclTransport(object):
         self.handle = self.rt.dtp_rccl_create(idbuf, self.rank, self.world, self.device)
         if not self.handle:
             raise RuntimeError("ncclCommInitRank failed (rank %d of %d)" % (self.rank, self.world))
+        _live.add(self)
 
     @staticmethod
     def _stream():

@@ -6,6 +6,9 @@ The reference hard-codes every setting as a Python literal; the same literals ar
 here and a thin CLI overlay makes the benchmark configs selectable.
 """
 import argparse
+import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (multi-process RCCL on this pool)
 
 import torch
 
