@@ -39,10 +39,16 @@ def main():
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--grad-dtype", default=os.environ.get("DTP_BENCH_GRAD_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--lr", type=float, default=0.001)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (multi-process plumbing on a one-GPU box)")
     ap.add_argument("--grad-accum", type=int, default=1,
                     help="micro-batches per optimizer step (BASELINE config 4): the per-GPU batch is split "
                          "into this many micro-steps, all-reduce only on the last one (no_sync)")
     args = ap.parse_args()
+    if os.environ.get("DTP_BENCH_DUMP_AFTER"):      # debugging aid: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["DTP_BENCH_DUMP_AFTER"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -50,11 +56,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from distributed_training_pytorch_amd.data.synthetic import DeviceBatchSource
     from distributed_training_pytorch_amd.models.vgg16 import VGG16
@@ -91,11 +102,19 @@ def main():
     def fence():
         torch.cuda.synchronize()          # drain compute + gradient-comm streams before the barrier
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    verbose = os.environ.get("DTP_BENCH_VERBOSE") == "1"
+    for i in range(args.warmup):
         loss = step()
+        if verbose:
+            torch.cuda.synchronize()
+            print("[bench rank %d] warm-up step %d done, loss %.4f" % (rank, i, float(loss.detach())),
+                  file=sys.stderr, flush=True)
     fence()
     exposed0 = dp.reducer.exposed_ms_total()
     t0 = time.perf_counter()
@@ -104,7 +123,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     exposed = (dp.reducer.exposed_ms_total() - exposed0) / max(1, args.steps)
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
