@@ -31,7 +31,7 @@ def _pil():
 
 
 class ExampleDataset(Dataset):
-    def __init__(self, data_path, labels, height, width, phase, seed=0, normalize=True, prob=0.5):
+    def __init__(self, data_path, labels, height, width, phase, seed=0, normalize=True, prob=0.5, uint8=False):
         super().__init__()
         self.data_path = data_path
         self.labels = list(labels)
@@ -39,6 +39,9 @@ class ExampleDataset(Dataset):
         self.phase = phase
         self.prob = prob
         self.normalize = normalize
+        # uint8=True: return raw CHW uint8 pixels (4x fewer bytes over PCIe); the /255, mean and std
+        # are then fused into the first convolution's ingest kernel (ConvFirst.set_input_normalization)
+        self.uint8 = bool(uint8)
         self.data_list = self._load_data(data_path, self.labels)
         self.rng = random.Random(seed)
         self.mean = np.asarray(IMAGENET_MEAN, dtype=np.float32).reshape(3, 1, 1)
@@ -98,6 +101,8 @@ class ExampleDataset(Dataset):
         img = Image.open(path).convert("RGB").resize((self.width, self.height), Image.BILINEAR)
         if self.phase == "train":
             img = self._augment(img)
+        if self.uint8:
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))), lb
         a = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0
         if self.normalize:
             a = (a - self.mean) / self.std

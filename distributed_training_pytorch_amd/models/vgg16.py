@@ -111,7 +111,15 @@ class VGG16(nn.Module):
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
         self._attach_arena()     # parameters were re-created/moved: re-home them in a fresh arena
+        if getattr(self, "input_norm", None) is not None:
+            self.set_input_normalization(*self.input_norm)      # constants follow the device
         return out
+
+    def set_input_normalization(self, scale=1.0, mean=None, std=None):
+        """Accept raw (e.g. uint8) images: ``(x*scale - mean)/std`` is applied inside the first
+        convolution's ingest kernel on the GPU (a plain tensor op on the CPU path)."""
+        self.input_norm = (float(scale), None if mean is None else tuple(mean), None if std is None else tuple(std))
+        self.backbone[0].conv[0].set_input_normalization(scale, mean, std)
 
     def set_grad_dtype(self, dtype):
         self.grad_dtype = dtype

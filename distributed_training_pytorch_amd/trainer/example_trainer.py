@@ -54,6 +54,7 @@ class ExampleTrainer(Trainer):
                  batch_norm=False,
                  grad_dtype=torch.float32,
                  fp8_classifier=False,
+                 uint8_input=False,
                  **engine_kwargs):
         self.train_path = train_path
         self.val_path = val_path
@@ -65,6 +66,8 @@ class ExampleTrainer(Trainer):
         self.batch_norm = batch_norm
         self.grad_dtype = grad_dtype
         self.fp8_classifier = fp8_classifier
+        # ship uint8 pixels host->device and normalise inside the conv1 ingest kernel
+        self.uint8_input = bool(uint8_input)
         super().__init__(max_epoch, batch_size, pin_memory, have_validate, save_best_for, save_period,
                          save_folder, snapshot_path, logger, **engine_kwargs)
 
@@ -72,8 +75,9 @@ class ExampleTrainer(Trainer):
     def _dataset(self, path, phase, default_len, seed):
         n = _synthetic_len(path, default_len)
         if n is not None:
-            return SyntheticImageDataset(n, len(self.labels), self.height, self.width, seed=seed)
-        return ExampleDataset(path, self.labels, self.height, self.width, phase=phase)
+            return SyntheticImageDataset(n, len(self.labels), self.height, self.width, seed=seed,
+                                         uint8=self.uint8_input)
+        return ExampleDataset(path, self.labels, self.height, self.width, phase=phase, uint8=self.uint8_input)
 
     def build_train_dataset(self):
         return self._dataset(self.train_path, "train", 1024, seed=0)
@@ -83,8 +87,20 @@ class ExampleTrainer(Trainer):
 
     # model / loss / optimiser -----------------------------------------------------------------
     def build_model(self):
-        return VGG16(3, len(self.labels), True, batch_norm=self.batch_norm, grad_dtype=self.grad_dtype,
-                     fp8_classifier=self.fp8_classifier)
+        model = VGG16(3, len(self.labels), True, batch_norm=self.batch_norm, grad_dtype=self.grad_dtype,
+                      fp8_classifier=self.fp8_classifier)
+        if self.uint8_input:
+            model.set_input_normalization(*self.input_normalization())
+        return model
+
+    def input_normalization(self):
+        """(scale, mean, std) that turn the dataset's uint8 pixels into what the float pipeline
+        feeds the network: ImageNet statistics for image folders, the generator's affine map for
+        the synthetic set."""
+        if _synthetic_len(self.train_path, 1) is not None:
+            return 1.0 / 40.0, (128.0 / 40.0,) * 3, (1.0, 1.0, 1.0)
+        from ..data.image_folder import IMAGENET_MEAN, IMAGENET_STD
+        return 1.0 / 255.0, tuple(IMAGENET_MEAN), tuple(IMAGENET_STD)
 
     def build_criterion(self):
         return SoftmaxCrossEntropy()

@@ -33,6 +33,8 @@ def parse_args(argv=None):
     ap.add_argument("--snapshot", default=None, help="resume from this snapshot (e.g. runs/weights/last.pth)")
     ap.add_argument("--no-validate", action="store_true")
     ap.add_argument("--batch-norm", action="store_true", help="VGG16-BN variant")
+    ap.add_argument("--uint8-input", action="store_true",
+                    help="ship uint8 pixels to the GPU; /255, mean and std are fused into the conv1 ingest kernel")
     ap.add_argument("--fp8-classifier", action="store_true", help="linear1/linear2 forward GEMMs in OCP e4m3 (GPU)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--grad-accum", type=int, default=1)
@@ -67,7 +69,7 @@ if __name__ == "__main__":
                              snapshot_path=args.snapshot,
                              logger=logger,
                              lr=args.lr,
-                             batch_norm=args.batch_norm, fp8_classifier=args.fp8_classifier,
+                             batch_norm=args.batch_norm, fp8_classifier=args.fp8_classifier, uint8_input=args.uint8_input,
                              grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32,
                              grad_accum_steps=args.grad_accum,
                              num_workers=args.num_workers,

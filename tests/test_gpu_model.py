@@ -399,3 +399,31 @@ def test_fp8_classifier_forward_and_training():
         m8.eval()                                    # eval top-1 pass runs on the fp8 path (running
         acc = float(top1_hits(m8(x), y)) / 16        # stats after 30 steps are still far from the batch's)
     assert 0.0 <= acc <= 1.0
+
+
+def test_uint8_ingest_matches_float_input_on_gpu():
+    """uint8 NCHW batch + (x*scale - mean)/std fused into the conv1 ingest kernel == feeding the
+    already-normalised float batch; backward runs through the same kernel (uint8 source)."""
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    _, gpu = _models(seed=9)
+    torch.manual_seed(10)
+    xu = torch.randint(0, 256, (8, 3, 64, 64), dtype=torch.uint8, device="cuda")
+    y = torch.randint(0, 3, (8,), device="cuda")
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    xf = (xu.float() / 255.0 - torch.tensor(mean, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std, device="cuda").view(1, 3, 1, 1)
+    crit = SoftmaxCrossEntropy()
+    a = gpu.param_arena
+    a.zero_grad()
+    out_f = gpu(xf)
+    crit(out_f, y).backward()
+    torch.cuda.synchronize()
+    g_f = a.flat_grad.clone()
+    gpu.set_input_normalization(1.0 / 255.0, mean, std)
+    a.zero_grad()
+    out_u = gpu(xu)
+    crit(out_u, y).backward()
+    torch.cuda.synchronize()
+    scale = out_f.abs().max().item()
+    assert (out_u - out_f).abs().max().item() < 0.02 * scale + 1e-4
+    cos = torch.nn.functional.cosine_similarity(a.flat_grad.flatten(), g_f.flatten(), dim=0).item()
+    assert cos > 0.99, cos

@@ -314,3 +314,21 @@ def test_reducer_counts_each_parameter_once_per_pass():
     for p in ps:                                              # next pass starts from a clean slate
         red.mark_ready(p)
     assert len(tr.launched) == 2
+
+
+def test_uint8_input_pipeline_matches_float_pipeline():
+    """uint8 pixels + normalisation fused into the first layer == the float dataset path."""
+    from distributed_training_pytorch_amd.data.synthetic import SyntheticImageDataset
+    f = SyntheticImageDataset(6, 3, 32, 32, seed=3)
+    u = SyntheticImageDataset(6, 3, 32, 32, seed=3, uint8=True)
+    xf = torch.stack([f[i][0] for i in range(6)])
+    xu = torch.stack([u[i][0] for i in range(6)])
+    assert xu.dtype == torch.uint8
+    torch.manual_seed(0)
+    m = VGG16(3, 3, True, dropout=0.0).eval()
+    with torch.no_grad():
+        ref = m(xf)
+        m.set_input_normalization(1.0 / 40.0, (128.0 / 40.0,) * 3, (1.0, 1.0, 1.0))
+        out = m(xu)
+    # the uint8 image is the float image rounded to 1/40 (and clamped): logits agree closely
+    assert (out - ref).abs().max().item() < 0.05 * ref.abs().max().item() + 1e-3
