@@ -1,0 +1,92 @@
+"""Base class / helper that turns ANY ``nn.Module`` built from the fused layers of ``ops.layers``
+(``ConvFirst``, ``Conv3x3``, ``MaxPool2x2``, ``AvgPoolFlatten``, ``Linear`` ...) into a model the
+kernels, the fused optimizers, the reducer and the hipGraph step can run.
+
+The reference's ``Trainer`` is model-agnostic — ``build_model()`` is a hook
+(``trainer/trainer.py:220-253``) and VGG16 is only the worked example — so the machinery VGG16
+needs (flat parameter arena, re-homing after ``.to(device)``, bf16 working copy refresh,
+contiguous ``state_dict`` entries) lives here and is reusable:
+
+    class TinyNet(FusedModel):
+        def __init__(self):
+            super().__init__()
+            self.c1 = ConvFirst(3, 64, relu=True, grad_premasked=True)
+            self.pool = MaxPool2x2(relu_mask=True)
+            self.flat = AvgPoolFlatten((7, 7))
+            self.fc = Linear(64 * 49, 10, out_fp32=True)
+            self.finalize()                      # builds the arena; call last in __init__
+
+        def forward(self, x):
+            x = self.prepare_input(x)            # refreshes the bf16 weight copy when needed
+            return self.fc(self.flat(self.pool(self.c1(x))))
+
+``attach_arena(module)`` does the same for an already-constructed plain ``nn.Module`` (one shot:
+call it again after moving the module to another device).
+"""
+import torch
+import torch.nn as nn
+
+from ..ops.layers import FusedLayer
+from .param_arena import ParamArena
+
+
+def attach_arena(module, grad_dtype=torch.float32):
+    """Re-home ``module``'s parameters in a fresh :class:`ParamArena` and bind every fused layer
+    to it.  Returns the arena (also stored as ``module.param_arena``)."""
+    arena = ParamArena(module, grad_dtype=grad_dtype)
+    object.__setattr__(module, "param_arena", arena)
+    on_gpu = arena.device.type == "cuda"
+    for m in module.modules():
+        if isinstance(m, FusedLayer):
+            object.__setattr__(m, "_arena", arena)
+            if on_gpu:
+                for p in m.parameters(recurse=False):
+                    arena.kernel_written.add(id(p))
+            m._derived, m._derived_epoch = {}, -1
+    return arena
+
+
+def _contiguous_state_dict_hook(module, state_dict, prefix, local_metadata):
+    """Emit standalone, contiguous fp32 tensors (not views of the arena)."""
+    for k in list(state_dict.keys()):
+        v = state_dict[k]
+        if torch.is_tensor(v) and k.startswith(prefix):
+            state_dict[k] = v.detach().clone(memory_format=torch.contiguous_format)
+    return state_dict
+
+
+class FusedModel(nn.Module):
+    def __init__(self, grad_dtype=torch.float32):
+        super().__init__()
+        self.grad_dtype = grad_dtype
+        self.param_arena = None
+        self._finalized = False
+
+    def finalize(self):
+        """Call at the end of ``__init__``: all parameters exist, build the arena."""
+        self._register_state_dict_hook(_contiguous_state_dict_hook)
+        self._finalized = True
+        self._attach_arena()
+        return self
+
+    def _attach_arena(self):
+        attach_arena(self, self.grad_dtype)
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        if self._finalized:
+            self._attach_arena()     # parameters were re-created/moved: re-home them in a fresh arena
+            self._after_rehome()
+        return out
+
+    def _after_rehome(self):
+        """Hook for subclasses that keep device-side constants (e.g. input normalisation)."""
+
+    def set_grad_dtype(self, dtype):
+        self.grad_dtype = dtype
+        self._attach_arena()
+
+    def prepare_input(self, x):
+        if x.is_cuda and self.param_arena is not None:
+            self.param_arena.refresh_lp()
+        return x

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, FusedLayer, Linear, MaxPool2x2,
                           ReLUMarker)
-from .param_arena import ParamArena
+from .fused_model import FusedModel
 
 
 class BatchNormNHWC(nn.BatchNorm2d):
@@ -59,13 +59,12 @@ class ConvBlock(nn.Module):
         return self.conv(x)
 
 
-class VGG16(nn.Module):
+class VGG16(FusedModel):
     def __init__(self, in_channels=3, out_channels=1, init_weights=True, batch_norm=False,
                  dropout=0.3, grad_dtype=torch.float32, fp8_classifier=False):
-        super().__init__()
+        super().__init__(grad_dtype=grad_dtype)
         self.fp8_classifier = bool(fp8_classifier)   # linear1/linear2 forward GEMMs in OCP e4m3
         self.batch_norm = batch_norm
-        self.grad_dtype = grad_dtype
         self.backbone = nn.Sequential(ConvBlock(in_channels, 64, first=True, batch_norm=batch_norm),
                                       ConvBlock(64, 128, batch_norm=batch_norm),
                                       ConvBlock(128, 256, num_layers=3, batch_norm=batch_norm),
@@ -83,9 +82,7 @@ class VGG16(nn.Module):
                               input_drop_p=dropout)
         if init_weights:
             self._initialize_weights()
-        self.param_arena = None
-        self._register_state_dict_hook(_contiguous_state_dict_hook)
-        self._attach_arena()
+        self.finalize()
 
     def _initialize_weights(self):
         for m in self.modules():
@@ -96,24 +93,10 @@ class VGG16(nn.Module):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.constant_(m.bias, 0)
 
-    # ------------------------------------------------------------------ arena management
-    def _attach_arena(self):
-        object.__setattr__(self, "param_arena", ParamArena(self, grad_dtype=self.grad_dtype))
-        on_gpu = self.param_arena.device.type == "cuda"
-        for m in self.modules():
-            if isinstance(m, FusedLayer):
-                object.__setattr__(m, "_arena", self.param_arena)
-                if on_gpu:
-                    for p in m.parameters(recurse=False):
-                        self.param_arena.kernel_written.add(id(p))
-                m._derived, m._derived_epoch = {}, -1
-
-    def _apply(self, fn, recurse=True):
-        out = super()._apply(fn, recurse)
-        self._attach_arena()     # parameters were re-created/moved: re-home them in a fresh arena
+    # ------------------------------------------------------------------ input normalisation
+    def _after_rehome(self):
         if getattr(self, "input_norm", None) is not None:
             self.set_input_normalization(*self.input_norm)      # constants follow the device
-        return out
 
     def set_input_normalization(self, scale=1.0, mean=None, std=None):
         """Accept raw (e.g. uint8) images: ``(x*scale - mean)/std`` is applied inside the first
@@ -121,27 +104,13 @@ class VGG16(nn.Module):
         self.input_norm = (float(scale), None if mean is None else tuple(mean), None if std is None else tuple(std))
         self.backbone[0].conv[0].set_input_normalization(scale, mean, std)
 
-    def set_grad_dtype(self, dtype):
-        self.grad_dtype = dtype
-        self._attach_arena()
-
     def forward(self, x):
-        if x.is_cuda:
-            self.param_arena.refresh_lp()
+        x = self.prepare_input(x)
         x = self.backbone(x)
         x = self.avgpool(x)
         x = self.linear1(x)      # + ReLU + dropout fused
         x = self.linear2(x)
         return self.linear3(x)
-
-
-def _contiguous_state_dict_hook(module, state_dict, prefix, local_metadata):
-    """Emit standalone, contiguous fp32 tensors (not views of the 537 MB arena)."""
-    for k in list(state_dict.keys()):
-        v = state_dict[k]
-        if torch.is_tensor(v) and k.startswith(prefix):
-            state_dict[k] = v.detach().clone(memory_format=torch.contiguous_format)
-    return state_dict
 
 
 def vgg16_bn(in_channels=3, out_channels=1, **kw):

@@ -32,7 +32,7 @@ def _arena_of(layer):
     if a is None:
         raise RuntimeError(
             "%s runs on the GPU only inside a model that owns a ParamArena "
-            "(call models.attach_arena(model) after moving it to the device)" % type(layer).__name__)
+            "(subclass models.FusedModel, or call models.attach_arena(model) after moving it to the device)" % type(layer).__name__)
     return a
 
 

@@ -23,6 +23,62 @@ def _allclose_across_ranks(t, atol=0.0):
     return float((hi - lo).abs().max()) <= atol
 
 
+def scenario_gpu_shared(out):
+    """Two ranks SHARE cuda:0 (one-GPU box) over gloo: the multi-process GPU path — parameter
+    broadcast, arena-range buckets, kernel-side ready notifications, all-reduce overlapped with the
+    HIP backward kernels, fused optimizer — on a small user-defined fused model, several steps."""
+    from distributed_training_pytorch_amd.models import FusedModel
+    from distributed_training_pytorch_amd.ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, Linear,
+                                                             MaxPool2x2, SoftmaxCrossEntropy)
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+
+    class TinyNet(FusedModel):
+        def __init__(self):
+            super().__init__()
+            self.c1 = ConvFirst(3, 64, relu=True, grad_premasked=True)
+            self.c2 = Conv3x3(64, 128, relu=True, input_is_relu_out=True, grad_premasked=True)
+            self.pool = MaxPool2x2(relu_mask=True)
+            self.flat = AvgPoolFlatten((2, 2))
+            self.fc1 = Linear(128 * 4, 256, relu=True, grad_premasked=True)
+            self.fc2 = Linear(256, 4, out_fp32=True, input_is_relu_out=True)
+            self.finalize()
+
+        def forward(self, x):
+            x = self.prepare_input(x)
+            return self.fc2(self.fc1(self.flat(self.pool(self.c2(self.c1(x))))))
+
+    torch.manual_seed(100 + rank)                 # different init per rank: broadcast must fix it
+    net = TinyNet().to(dev)
+    dp = DataParallel(net, bucket_cap_mb=0.05, first_bucket_mb=0.01)
+    assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
+    opt = FusedSGD(net, lr=0.05, momentum=0.9)
+    crit = SoftmaxCrossEntropy()
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(16 * world, 3, 32, 32, generator=g)
+    Y = torch.randint(0, 4, (16 * world,), generator=g)
+    xs, ys = X[rank::world].to(dev), Y[rank::world].to(dev)
+    a = net.param_arena
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        loss = crit(dp(xs), ys)
+        loss.backward()
+        torch.cuda.synchronize()
+        gsum = a.flat_grad.float().cpu()
+        assert _allclose_across_ranks(gsum), "step %d: averaged gradients differ across ranks" % it
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    assert all(l == l for l in losses), losses
+    assert _allclose_across_ranks(a.flat_master.cpu()), "parameters diverged across ranks"
+    assert dp.reducer.stats["launched"] == 6 * len(dp.reducer.buckets)
+    dp.close()
+    open(os.path.join(out, "losses.%d" % rank), "w").write(json.dumps(dict(losses=losses)))
+
+
 def scenario_reducer(out):
     """Bucketed reducer == single-process large-batch gradient; no_sync accumulates; params stay
     identical across ranks."""
@@ -122,7 +178,8 @@ def scenario_fault(out):
 if __name__ == "__main__":
     scenario, out = sys.argv[1], sys.argv[2]
     penv.ddp_setup("gloo", timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
-    {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault}[scenario](out)
+    {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault,
+     "gpu_shared": scenario_gpu_shared}[scenario](out)
     comm.barrier()
     open(os.path.join(out, "ok.%d" % dist.get_rank()), "w").write("ok")
     penv.destroy_process()

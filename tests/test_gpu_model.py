@@ -427,3 +427,21 @@ def test_uint8_ingest_matches_float_input_on_gpu():
     assert (out_u - out_f).abs().max().item() < 0.02 * scale + 1e-4
     cos = torch.nn.functional.cosine_similarity(a.flat_grad.flatten(), g_f.flatten(), dim=0).item()
     assert cos > 0.99, cos
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
+    """Multi-process GPU path on a one-GPU box: two ranks share cuda:0, process group over gloo,
+    a small user-defined FusedModel, six optimizer steps; gradients and parameters must be
+    identical across ranks after every all-reduce (tests/dist_worker.py::scenario_gpu_shared)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTP_TRANSPORT="torch", OMP_NUM_THREADS="2", DTP_PG_TIMEOUT_S="60")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29750 + os.getpid() % 100),
+           os.path.join(root, "tests", "dist_worker.py"), "gpu_shared", str(tmp_path)]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=110)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.0", "ok.1"]

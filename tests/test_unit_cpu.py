@@ -332,3 +332,51 @@ def test_uint8_input_pipeline_matches_float_pipeline():
         out = m(xu)
     # the uint8 image is the float image rounded to 1/40 (and clamped): logits agree closely
     assert (out - ref).abs().max().item() < 0.05 * ref.abs().max().item() + 1e-3
+
+
+def _tiny_fused_net():
+    from distributed_training_pytorch_amd.models import FusedModel
+    from distributed_training_pytorch_amd.ops.layers import AvgPoolFlatten, Conv3x3, ConvFirst, Linear, MaxPool2x2
+
+    class TinyNet(FusedModel):
+        """A user-defined model from the fused layers (the Trainer's build_model hook is generic)."""
+
+        def __init__(self, classes=4):
+            super().__init__()
+            self.c1 = ConvFirst(3, 64, relu=True, grad_premasked=True)
+            self.c2 = Conv3x3(64, 64, relu=True, input_is_relu_out=True, grad_premasked=True)
+            self.pool = MaxPool2x2(relu_mask=True)
+            self.flat = AvgPoolFlatten((2, 2))
+            self.fc1 = Linear(64 * 4, 64, relu=True, grad_premasked=True)
+            self.fc2 = Linear(64, classes, out_fp32=True, input_is_relu_out=True)
+            self.finalize()
+
+        def forward(self, x):
+            x = self.prepare_input(x)
+            return self.fc2(self.fc1(self.flat(self.pool(self.c2(self.c1(x))))))
+    return TinyNet
+
+
+def test_custom_fused_model_trains_with_fused_optimizer_cpu():
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    torch.manual_seed(0)
+    net = _tiny_fused_net()()
+    assert net.param_arena is not None and len(net.param_arena.params) == 8
+    sd = net.state_dict()
+    assert all(v.is_contiguous() for v in sd.values()) and sd["c2.weight"].shape == (64, 64, 3, 3)
+    opt = FusedSGD(net, lr=0.05, momentum=0.9)
+    crit = SoftmaxCrossEntropy()
+    x = torch.randn(16, 3, 16, 16)
+    y = torch.randint(0, 4, (16,))
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        loss = crit(net(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0] - 0.01 and all(b <= a + 1e-4 for a, b in zip(losses, losses[1:])), losses
+    net2 = _tiny_fused_net()()
+    net2.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        assert torch.allclose(net2.eval()(x), net.eval()(x), atol=1e-6)
