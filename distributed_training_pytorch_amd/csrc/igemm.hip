@@ -22,6 +22,7 @@
 // cuBLAS linear that the reference reaches through
 // model/vgg16.py:9-13,71-79.
 #include "dtp_common.h"
+#include <cstdlib>
 #include <type_traits>
 
 struct IgemmParams {
@@ -48,6 +49,7 @@ struct IgemmParams {
   int ksteps_total;
   int ksteps_per_split;
   int tiles_m, tiles_n;
+  int k_order;            // 3x3 reduction order: 0 = tap-major (tap, channel chunk), 1 = chunk-major (chunk, tap)
 };
 
 // 16x16x32 MFMA step on one 16-byte fragment pair.  FP8: the 16 bytes are 16 OCP e4m3 values, fed
@@ -136,7 +138,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
 
   auto stage = [&](int kt, int buf) {
     int tap = 0, cc = kt;
-    if (TAPS9) { tap = kt / cchunks; cc = kt - tap * cchunks; }
+    if (TAPS9) {
+      if (p.k_order) { cc = kt / 9; tap = kt - cc * 9; }
+      else { tap = kt / cchunks; cc = kt - tap * cchunks; }
+    }
     long koffA, koffB;
     if (TAPS9) {
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -212,8 +217,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     char* lB = lA + BM * 128;
     if (PF) {
       if (TAPS9) {
-        tap = (kt + 1) / cchunks;
-        cc = (kt + 1) - tap * cchunks;
+        if (p.k_order) { cc = (kt + 1) / 9; tap = (kt + 1) - cc * 9; }
+        else { tap = (kt + 1) / cchunks; cc = (kt + 1) - tap * cchunks; }
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         koffA = ((long)(dy * p.W + dx) * p.C + cc * 64) * 2;
         koffB = ((long)tap * p.C + cc * 64) * 2;
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int cc = T;
       tap = 0;
       if (TAPS9) {
-        tap = T / cchunks;
-        cc = T - tap * cchunks;
+        if (p.k_order) { cc = T / 9; tap = T - cc * 9; }
+        else { tap = T / cchunks; cc = T - tap * cchunks; }
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         koffA = ((long)(dy * p.W + dx) * p.C + cc * 64) * 2;
         koffB = ((long)tap * p.C + cc * 64) * 2;
@@ -629,6 +634,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
   p.seed_ptr = (const unsigned long long*)seed_ptr;
   p.dq_a = dq_a; p.dq_b = dq_b;
+  static const int k_order_env = std::getenv("DTP_IGEMM_KORDER") ? std::atoi(std::getenv("DTP_IGEMM_KORDER")) : 1;
+  p.k_order = k_order_env;
   if (fp8 && (!dq_a || !dq_b)) return -19;
   p.ksteps_total = taps * (C >> (fp8 ? 7 : 6));
   if (nsplit < 1) nsplit = 1;
