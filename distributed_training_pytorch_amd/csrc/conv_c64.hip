@@ -25,7 +25,8 @@ struct ConvC64Params {
   const char* Wt;        // [O][9*64] bf16
   const float* bias;     // [O] or null
   const char* mask_src;  // [N*H*W][O] bf16 or null
-  char* out;             // [N*H*W][O] bf16
+  char* out;             // [N*H*W][O] bf16   (POOL: [N*(H/2)*(W/2)][O], the 2x2-max-pooled output)
+  uint32_t* codes;       // POOL: [N*(H/2)*(W/2)][O/8] 4-bit (first-argmax, max > 0) codes for the pool backward
   const char* zero_page;
   int N, H, W;
   int S, RC, rows_per_chunk;
@@ -33,8 +34,8 @@ struct ConvC64Params {
   float mask_scale;
 };
 
-template <int O>
-__global__ __launch_bounds__(O * 2) void conv_c64_kernel(const ConvC64Params p) {
+template <int O, bool POOL>
+__global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params p) {
   constexpr int NW = O / 32;             // waves per workgroup (2 or 4)
   constexpr int X_SLOT = 40 * 128;
   constexpr int X_WI = 5;
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(O * 2) void conv_c64_kernel(const ConvC64Params p) 
   char* myO = lO + wave * 2048;
   const bool px_ok = (w0 + l31) < p.W;
 
+  uint32_t top_a = 0;
+  char* myT = lO + NW * 2048 + tid * 32;   // POOL: per-lane parking slot for the top row of a window
   stage_x(h0 - 1);
   stage_x(h0);
   stage_x(h0 + 1);
@@ -122,47 +125,134 @@ __global__ __launch_bounds__(O * 2) void conv_c64_kernel(const ConvC64Params p) 
         }
       }
     }
-    // ---- epilogue: (relu) -> bf16 -> per-wave LDS shuffle -> 16-byte row-segment stores
+    if constexpr (POOL) {
+      // ---- fused ReLU + 2x2/s2 max-pool: the full-resolution output is never written.  Lane =
+      // (pixel l31, hb); horizontal partner = lane ^ 1; the top row of each window waits in
+      // registers for the bottom row.  Tie rule = torch's (first maximum in (0,0),(0,1),(1,0),(1,1)
+      // order), evaluated on the bf16-rounded, ReLU'd values like the stand-alone pool kernel.
+      float hm[16];
+      uint32_t ha = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[q * 4 + e];
-        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+      for (int r = 0; r < 16; ++r) {
+        const float v = bf16_to_f32(f32_to_bf16(fmaxf(acc[r], 0.f)));
+        const float o = __shfl_xor(v, 1);
+        const bool right = o > v;                      // meaningful on even-pixel lanes
+        hm[r] = right ? o : v;
+        ha |= (right ? 1u : 0u) << (2 * r);
       }
-      u32x2_t pk;
-      pk[0] = pack_bf16x2(v[0], v[1]);
-      pk[1] = pack_bf16x2(v[2], v[3]);
-      const int slot8 = (2 * q + hb) ^ (l31 & 7);            // 8-byte slot = couts 8q + 4hb .. +3
-      *(u32x2_t*)(myO + l31 * 64 + slot8 * 8) = pk;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const size_t row_px = img_px + (size_t)h * p.W + w0;
+      if (((h - h0) & 1) == 0) {
+        // park the top row in this lane's private LDS strip (bf16 pairs): keeps the kernel at two
+        // waves per SIMD (the filter slice already owns 144 VGPRs)
+        u32x4_t t0, t1;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int id = lane + 64 * r;                           // 128 chunks of 16 B: (px, c16)
-      const int px = id >> 2, c16 = id & 3;
-      const int x7 = px & 7;
-      u32x4_t v;
-      const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
-      const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-      if ((w0 + px) < p.W) {
-        const size_t goff = ((row_px + px) * O + wave * 32 + c16 * 8) * 2;
-        if (p.mask_src) {
-          const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
+        for (int e = 0; e < 4; ++e) {
+          t0[e] = pack_bf16x2(hm[2 * e], hm[2 * e + 1]);
+          t1[e] = pack_bf16x2(hm[8 + 2 * e], hm[8 + 2 * e + 1]);
+        }
+        *(u32x4_t*)(myT) = t0;
+        *(u32x4_t*)(myT + 16) = t1;
+        top_a = ha;
+      } else {
+        float top_m[16];
+        {
+          const u32x4_t t0 = *(const u32x4_t*)(myT), t1 = *(const u32x4_t*)(myT + 16);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint32_t mw = mk[e], vw = v[e];
-            const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
-            const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
-            const float a = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
-            const float b = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
-            v[e] = pack_bf16x2(a, b);
+            top_m[2 * e] = __uint_as_float(t0[e] << 16);
+            top_m[2 * e + 1] = __uint_as_float(t0[e] & 0xFFFF0000u);
+            top_m[8 + 2 * e] = __uint_as_float(t1[e] << 16);
+            top_m[8 + 2 * e + 1] = __uint_as_float(t1[e] & 0xFFFF0000u);
           }
         }
-        *(u32x4_t*)(p.out + goff) = v;
+        uint32_t hc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float m4[4];
+          uint32_t nib = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = q * 4 + e;
+            float m = top_m[r];
+            uint32_t arg = (top_a >> (2 * r)) & 1u;
+            if (hm[r] > m) { m = hm[r]; arg = 2u + ((ha >> (2 * r)) & 1u); }
+            m4[e] = m;
+            nib |= (arg | (m > 0.f ? 4u : 0u)) << (4 * e);
+          }
+          hc[q] = nib;                                 // channels 8q + 4hb .. +3 of this wave's 32
+          u32x2_t pk;
+          pk[0] = pack_bf16x2(m4[0], m4[1]);
+          pk[1] = pack_bf16x2(m4[2], m4[3]);
+          const int pp = l31 >> 1;                     // pooled pixel within the strip (even lanes)
+          const int slot8 = (2 * q + hb) ^ (pp & 7);
+          if ((l31 & 1) == 0) *(u32x2_t*)(myO + pp * 64 + slot8 * 8) = pk;
+        }
+        // codes: lane hb = 0 holds nibbles 0-3 of each 8-channel group, its partner (lane + 32) 4-7
+        const uint32_t c01 = hc[0] | (hc[1] << 16), c23 = hc[2] | (hc[3] << 16);
+        const uint32_t o01 = __shfl_xor(c01, 32), o23 = __shfl_xor(c23, 32);
+        __builtin_amdgcn_wave_barrier();
+        const int OHp = p.H >> 1, OWp = p.W >> 1;
+        const size_t prow = ((size_t)n * OHp + (h >> 1)) * OWp + (w0 >> 1);
+        {
+          const int px = lane >> 2, c16 = lane & 3;    // 16 pooled pixels x 4 chunks of 16 B
+          const int x7 = px & 7;
+          u32x4_t v;
+          const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
+          const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+          if ((w0 + 2 * px) < p.W) *(u32x4_t*)(p.out + ((prow + px) * O + wave * 32 + c16 * 8) * 2) = v;
+        }
+        if (hb == 0 && (l31 & 1) == 0 && (w0 + l31) < p.W) {
+          u32x4_t cw;
+          cw[0] = (c01 & 0xFFFFu) | (o01 << 16);
+          cw[1] = (c01 >> 16) | (o01 & 0xFFFF0000u);
+          cw[2] = (c23 & 0xFFFFu) | (o23 << 16);
+          cw[3] = (c23 >> 16) | (o23 & 0xFFFF0000u);
+          *(u32x4_t*)(p.codes + (prow + (l31 >> 1)) * (O / 8) + wave * 4) = cw;
+        }
+      }
+    } else {
+      // ---- epilogue: (relu) -> bf16 -> per-wave LDS shuffle -> 16-byte row-segment stores
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[q * 4 + e];
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        u32x2_t pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        const int slot8 = (2 * q + hb) ^ (l31 & 7);            // 8-byte slot = couts 8q + 4hb .. +3
+        *(u32x2_t*)(myO + l31 * 64 + slot8 * 8) = pk;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const size_t row_px = img_px + (size_t)h * p.W + w0;
+  #pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int id = lane + 64 * r;                           // 128 chunks of 16 B: (px, c16)
+        const int px = id >> 2, c16 = id & 3;
+        const int x7 = px & 7;
+        u32x4_t v;
+        const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
+        const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+        if ((w0 + px) < p.W) {
+          const size_t goff = ((row_px + px) * O + wave * 32 + c16 * 8) * 2;
+          if (p.mask_src) {
+            const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t mw = mk[e], vw = v[e];
+              const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
+              const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
+              const float a = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+              const float b = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+              v[e] = pack_bf16x2(a, b);
+            }
+          }
+          *(u32x4_t*)(p.out + goff) = v;
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -171,8 +261,9 @@ __global__ __launch_bounds__(O * 2) void conv_c64_kernel(const ConvC64Params p) 
 }
 
 // X [N,H,W,64] bf16, Wt [O][576] bf16 -> out [N,H,W,O] bf16 (O = 64 or 128)
+// codes != null: fused ReLU + 2x2 max-pool epilogue; out is then [N,H/2,W/2,O] and codes [N,H/2,W/2,O/8] uint32
 extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, const void* mask_src, void* out,
-                            const void* zero_page, int N, int H, int W, int O, int relu, float mask_scale,
+                            void* codes, const void* zero_page, int N, int H, int W, int O, int relu, float mask_scale,
                             hipStream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || (O != 64 && O != 128)) return -10;
   ConvC64Params p;
@@ -190,12 +281,23 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
   p.RC = (H + p.rows_per_chunk - 1) / p.rows_per_chunk;
   const long grid = units * p.RC;
   if (grid > 0x7FFFFFFFL) return -11;
+  p.codes = (uint32_t*)codes;
+  if (codes) {   // fused ReLU + max-pool: windows must not straddle row chunks or the image edge
+    if ((H & 1) || (W & 1) || !relu || mask_src) return -12;
+    if (p.rows_per_chunk & 1) {
+      p.rows_per_chunk += 1;
+      p.RC = (H + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    }
+  }
+  const long grid2 = units * p.RC;
   if (O == 64) {
-    constexpr int lds = 4 * 40 * 128 + 2 * 2048;
-    hipLaunchKernelGGL(conv_c64_kernel<64>, dim3((unsigned)grid), dim3(128), lds, stream, p);
+    constexpr int lds = 4 * 40 * 128 + 2 * 2048 + 128 * 32;
+    if (codes) hipLaunchKernelGGL((conv_c64_kernel<64, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<64, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
   } else {
-    constexpr int lds = 4 * 40 * 128 + 4 * 2048;
-    hipLaunchKernelGGL(conv_c64_kernel<128>, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    constexpr int lds = 4 * 40 * 128 + 4 * 2048 + 256 * 32;
+    if (codes) hipLaunchKernelGGL((conv_c64_kernel<128, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<128, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
   }
   return DTP_CHECK_LAUNCH();
 }

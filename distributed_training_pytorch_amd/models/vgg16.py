@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, FusedLayer, Linear, MaxPool2x2,
-                          ReLUMarker)
+                          ReLUMarker, conv_relu_pool)
 from .fused_model import FusedModel
 
 
@@ -54,8 +54,21 @@ class ConvBlock(nn.Module):
             layers.append(ReLUMarker(active=batch_norm))
         layers.append(MaxPool2x2(relu_mask=not batch_norm))
         self.conv = nn.Sequential(*layers)
+        self.batch_norm = batch_norm
 
     def forward(self, x):
+        if x.is_cuda and not self.batch_norm:
+            # last conv + ReLU + pool as one kernel where the shapes allow it (block 1: the
+            # 1.6 GB pre-pool activation at batch 256 is neither written nor re-read)
+            mods = list(self.conv)
+            for m in mods[:-3]:
+                x = m(x)
+            y = conv_relu_pool(mods[-3], x) if isinstance(mods[-1], MaxPool2x2) and mods[-1].relu_mask else None
+            if y is not None:
+                return y
+            for m in mods[-3:]:
+                x = m(x)
+            return x
         return self.conv(x)
 
 

@@ -7,6 +7,7 @@ launches on the caller's current HIP stream.  Tensors are internal-layout: activ
 ``[out, in]``.
 """
 import ctypes as _ctypes
+import os as _os
 
 import torch
 
@@ -140,6 +141,7 @@ class _ColsumSlot(object):
 
 
 colsum_slot = _ColsumSlot()
+fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
 
 
@@ -192,9 +194,9 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     return out
 
 
-def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale):
+def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None):
     """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip)."""
-    rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out),
+    rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out), ptr(codes),
                                  ptr(workspace.zero_page(x.device)), N, H, W, O, int(relu), float(mask_scale),
                                  stream())
     check(rc, "conv_c64")
@@ -222,6 +224,29 @@ def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
     if C == 64 and Cout in (64, 128) and "igemm" not in _overrides:
         return _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0)
     return _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0)
+
+
+def conv_pool_fusable(C, Cout, H, W):
+    """Shapes for which conv3x3 + ReLU + 2x2 max-pool run as ONE kernel (conv_c64 POOL epilogue)."""
+    return (fuse_conv_pool and C == 64 and Cout in (64, 128) and H % 2 == 0 and W % 2 == 0
+            and "igemm" not in _overrides)
+
+
+def conv3x3_relu_pool_fprop(x, w, bias):
+    """(maxpool2x2(relu(conv3x3(x, w) + bias)), codes): the full-resolution activation is never
+    written — backward needs only the pooled output's 4-bit (argmax, positive) codes."""
+    _need(x, BF16, "x")
+    _need(w, BF16, "w")
+    N, H, W, C = x.shape
+    Cout = w.shape[0]
+    if w.numel() != Cout * 9 * C or not conv_pool_fusable(C, Cout, H, W):
+        raise ValueError("conv3x3_relu_pool_fprop: unsupported shapes x=%s w=%s" % (tuple(x.shape), tuple(w.shape)))
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    y = torch.empty((N, H // 2, W // 2, Cout), dtype=BF16, device=x.device)
+    codes = torch.empty((N, H // 2, W // 2, Cout // 8), dtype=torch.int32, device=x.device)
+    _conv_c64(x, w, bias, None, y, N, H, W, Cout, True, 1.0, codes=codes)
+    return y, codes
 
 
 def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):

@@ -95,6 +95,49 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _Conv3x3ReluPoolFn(torch.autograd.Function):
+    """conv3x3 + bias + ReLU + 2x2 max-pool as one kernel (64-reduction-channel layers): the
+    pre-pool activation never reaches HBM.  Backward: pool backward from the 4-bit codes (ReLU
+    mask included, bias-gradient column sums left behind), then the usual wgrad / dgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, layer):
+        arena = _arena_of(layer)
+        y, codes = K.conv3x3_relu_pool_fprop(x, arena.lp(weight), bias.detach())
+        ctx.layer = layer
+        ctx.save_for_backward(x, codes, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dyp):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        x, codes, weight, bias = ctx.saved_tensors
+        N, H, W, _ = x.shape
+        Co, Ci = weight.shape[0], weight.shape[1]
+        dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
+        K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+        return dx, None, None, None
+
+
+def conv_relu_pool(conv, x):
+    """Fused forward of ``conv`` (a :class:`Conv3x3` with ReLU) followed by MaxPool2x2, or None when
+    this layer/shape is not eligible (caller then runs the two modules)."""
+    if (not x.is_cuda or not isinstance(conv, Conv3x3) or not conv.relu or not conv.grad_premasked
+            or conv.bias is None or x.dim() != 4):
+        return None
+    if not K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2]):
+        return None
+    return _Conv3x3ReluPoolFn.apply(x, conv.weight, conv.bias, conv)
+
+
 class Conv3x3(FusedLayer):
     """3x3, stride 1, pad 1 convolution (+bias, +ReLU fused).  ``weight`` keeps torch's logical
     ``[Cout, Cin, 3, 3]`` shape (checkpoint compatibility with reference model/vgg16.py:9,12)."""

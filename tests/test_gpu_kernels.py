@@ -525,3 +525,24 @@ def test_wgrad_8phase_schedule(shape):
         k._overrides.pop("wgrad")
     refl = dl.float()[:, :Nout].t() @ xl.float()
     _close(gl, refl, 2e-2, 2e-2 * refl.abs().max().item(), "wgrad8 linear")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 28, 36, 128), (1, 64, 70, 64), (2, 224, 224, 64)])
+def test_fused_conv_relu_pool_matches_separate_kernels(shape):
+    """conv_c64 POOL epilogue == conv3x3_fprop followed by maxpool2x2_fwd, bit for bit (pooled
+    activations AND the 4-bit argmax/positive codes), incl. strips with tails (W = 36, 70)."""
+    k = _k()
+    N, H, W, Co = shape
+    torch.manual_seed(15)
+    x = _rand(N, H, W, 64)
+    w = _rand(Co, 9 * 64, scale=(2.0 / (9 * 64)) ** 0.5)
+    b = torch.randn(Co, device="cuda") * 0.1
+    y_full = k.conv3x3_fprop(x, w, b, relu=True)
+    y_ref, codes_ref = k.maxpool2x2_fwd(y_full, want_idx=True)
+    y, codes = k.conv3x3_relu_pool_fprop(x, w, b)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(codes, codes_ref)
+    dyp = _rand(*y.shape)
+    dx_ref = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes_ref, in_shape=tuple(y_full.shape))
+    dx = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes, in_shape=tuple(y_full.shape))
+    assert torch.equal(dx, dx_ref)
