@@ -1,0 +1,34 @@
+// Host-only stand-in for <hip/hip_runtime.h>: just enough of the stream/event API for
+// csrc/runtime/rccl_transport.cpp, recording every call so that the transport's host logic
+// (event ring, ordering of record/wait/collective, error paths, teardown) can run under
+// AddressSanitizer/UBSan on a CPU-only box.  Not used in any product build.
+#pragma once
+#include <cstddef>
+#include <string>
+#include <vector>
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+struct MockStream { int id; bool non_blocking; int priority; };
+struct MockEvent { int id; int records; const MockStream* last_stream; bool destroyed; };
+typedef MockStream* hipStream_t;
+typedef MockEvent* hipEvent_t;
+constexpr unsigned hipEventDisableTiming = 2;
+constexpr unsigned hipStreamNonBlocking = 1;
+
+struct MockLog {
+  std::vector<std::string> calls;
+  int events_created = 0, events_destroyed = 0, streams_created = 0, streams_destroyed = 0;
+  int fail_event_create_after = -1;     // inject hipEventCreate failures
+};
+MockLog& mock_log();
+
+hipError_t hipSetDevice(int);
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi);
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventDestroy(hipEvent_t e);

@@ -1,0 +1,137 @@
+// Host-logic test of the native RCCL transport against mock HIP/RCCL (built with
+// -fsanitize=address,undefined by tests/test_native_host.py).  Checks, for a long run of
+// launches: every collective is preceded by "record(producer) -> wait(comm stream)", waits hand
+// the comm stream back to the consumer, the event ring is bounded and re-used, statistics add up,
+// argument validation rejects bad calls, and destroy releases every event / stream / communicator.
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "mock/hip/hip_runtime.h"
+#include "mock/rccl/rccl.h"
+
+// ---- mock implementation -----------------------------------------------------------------------
+static MockLog g_log;
+MockLog& mock_log() { return g_log; }
+static void logc(const std::string& s) { g_log.calls.push_back(s); }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio) {
+  *s = new MockStream{100 + g_log.streams_created++, (flags & hipStreamNonBlocking) != 0, prio};
+  return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s) { ++g_log.streams_destroyed; delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { logc("sync:" + std::to_string(s ? s->id : 0)); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
+  assert(e && !e->destroyed && e->records > 0 && "waiting on an event that was never recorded");
+  logc("wait:" + std::to_string(s ? s->id : 0) + ":on:" + std::to_string(e->last_stream ? e->last_stream->id : 0));
+  return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
+  if (g_log.fail_event_create_after >= 0 && g_log.events_created >= g_log.fail_event_create_after) return 2;
+  *e = new MockEvent{g_log.events_created++, 0, nullptr, false};
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+  assert(e && !e->destroyed);
+  ++e->records;
+  e->last_stream = s;
+  logc("record:" + std::to_string(s ? s->id : 0));
+  return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) { ++g_log.events_destroyed; e->destroyed = true; delete e; return hipSuccess; }
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { std::memset(id, 7, sizeof(*id)); return ncclSuccess; }
+static int g_comms = 0;
+ncclResult_t ncclCommInitRank(ncclComm_t* c, int world, ncclUniqueId id, int rank) {
+  assert(id.internal[5] == 7);
+  *c = new MockComm{rank, world, false};
+  ++g_comms;
+  return ncclSuccess;
+}
+ncclResult_t ncclCommDestroy(ncclComm_t c) { --g_comms; delete c; return ncclSuccess; }
+ncclResult_t ncclAllReduce(const void* s, void* r, size_t n, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c,
+                           hipStream_t st) {
+  assert(s == r && c && st && st->non_blocking);
+  logc("allreduce:" + std::to_string(st->id) + ":" + std::to_string(n) + ":" + std::to_string((int)dt) + ":" +
+       std::to_string((int)op));
+  return ncclSuccess;
+}
+ncclResult_t ncclBroadcast(const void*, void*, size_t n, ncclDataType_t, int root, ncclComm_t, hipStream_t st) {
+  logc("broadcast:" + std::to_string(st->id) + ":" + std::to_string(n) + ":" + std::to_string(root));
+  return ncclSuccess;
+}
+
+// ---- unit under test -----------------------------------------------------------------------------
+extern "C" {
+int dtp_rccl_unique_id(void* out, int out_bytes);
+int dtp_rccl_unique_id_bytes();
+void* dtp_rccl_create(const void* id_bytes, int rank, int world, int device);
+int dtp_rccl_allreduce_async(void* h, void* buf, size_t count, int dtype_kind, int average, hipStream_t producer);
+int dtp_rccl_wait(void* h, hipStream_t consumer);
+int dtp_rccl_broadcast(void* h, void* buf, size_t count, int dtype_kind, int root, hipStream_t stream);
+int dtp_rccl_sync(void* h);
+int dtp_rccl_stats(void* h, unsigned long long* launched, unsigned long long* bytes);
+int dtp_rccl_destroy(void* h);
+}
+
+int main() {
+  char id[256];
+  assert(dtp_rccl_unique_id_bytes() == (int)sizeof(ncclUniqueId));
+  assert(dtp_rccl_unique_id(id, 8) == -2);                       // buffer too small
+  assert(dtp_rccl_unique_id(id, sizeof(id)) == (int)sizeof(ncclUniqueId));
+  assert(dtp_rccl_create(id, 3, 2, 0) == nullptr);               // rank out of range
+  assert(dtp_rccl_create(id, 0, 0, 0) == nullptr);
+  void* t = dtp_rccl_create(id, 1, 4, 0);
+  assert(t && g_comms == 1 && g_log.streams_created == 1);
+
+  MockStream compute{1, false, 0};
+  float buf[64];
+  assert(dtp_rccl_allreduce_async(nullptr, buf, 64, 0, 1, &compute) == -2);
+  assert(dtp_rccl_allreduce_async(t, nullptr, 64, 0, 1, &compute) == -2);
+  assert(dtp_rccl_allreduce_async(t, buf, 0, 0, 1, &compute) == -2);
+
+  // 1000 steps x (7 bucket launches + 7 waits): far more events than the ring holds
+  unsigned long long want_bytes = 0;
+  for (int step = 0; step < 1000; ++step) {
+    for (int b = 0; b < 7; ++b) {
+      const size_t before = g_log.calls.size();
+      const int kind = b & 1;
+      assert(dtp_rccl_allreduce_async(t, buf, 64, kind, 1, &compute) == 0);
+      want_bytes += 64 * (kind ? 2 : 4);
+      // exactly: record on the producer, comm stream waits on it, collective on the comm stream
+      assert(g_log.calls.size() == before + 3);
+      assert(g_log.calls[before] == "record:1");
+      assert(g_log.calls[before + 1] == "wait:100:on:1");
+      assert(g_log.calls[before + 2].rfind("allreduce:100:64:", 0) == 0);
+      assert(g_log.calls[before + 2].substr(g_log.calls[before + 2].size() - 2) == ":4");   // ncclAvg
+    }
+    for (int b = 0; b < 7; ++b) {
+      const size_t before = g_log.calls.size();
+      assert(dtp_rccl_wait(t, &compute) == 0);
+      assert(g_log.calls[before] == "record:100" && g_log.calls[before + 1] == "wait:1:on:100");
+    }
+    if (step % 100 == 0) g_log.calls.clear();
+  }
+  assert(g_log.events_created <= 64 && "event ring must be bounded");
+  unsigned long long launched = 0, bytes = 0;
+  assert(dtp_rccl_stats(t, &launched, &bytes) == 0 && launched == 7000 && bytes == want_bytes);
+
+  g_log.calls.clear();
+  assert(dtp_rccl_broadcast(t, buf, 64, 0, 0, &compute) == 0);
+  assert(g_log.calls.size() == 5 && g_log.calls[2] == "broadcast:100:64:0" && g_log.calls[4] == "wait:1:on:100");
+  assert(dtp_rccl_sync(t) == 0);
+  assert(dtp_rccl_destroy(t) == 0);
+  assert(g_comms == 0 && g_log.streams_destroyed == 1 && g_log.events_destroyed == g_log.events_created);
+  assert(dtp_rccl_destroy(nullptr) == 0);
+
+  // event creation failure surfaces as an error code, not a crash or a leak
+  g_log = MockLog();
+  g_log.fail_event_create_after = 0;
+  void* t2 = dtp_rccl_create(id, 0, 1, 0);
+  assert(t2 && dtp_rccl_allreduce_async(t2, buf, 64, 0, 1, &compute) == -3);
+  assert(dtp_rccl_wait(t2, &compute) == -3);
+  assert(dtp_rccl_destroy(t2) == 0);
+  std::puts("transport host test ok");
+  return 0;
+}

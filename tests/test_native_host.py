@@ -1,0 +1,25 @@
+"""Host-side sanitizer tier for the C++ runtime: csrc/runtime/rccl_transport.cpp
+is compiled against mock HIP/RCCL headers (tests/native/mock) with AddressSanitizer + UBSan and
+driven by tests/native/transport_host_test.cpp — no GPU, no RCCL library needed."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs a host C++ compiler")
+def test_rccl_transport_host_logic_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "transport_host_test")
+    mock = os.path.join(ROOT, "tests", "native", "mock")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=all", "-static-libasan", "-I", mock, "-I", os.path.join(ROOT, "tests", "native"),
+           os.path.join(ROOT, "distributed_training_pytorch_amd", "csrc", "runtime", "rccl_transport.cpp"),
+           os.path.join(ROOT, "tests", "native", "transport_host_test.cpp"), "-o", exe, "-lpthread"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-4000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "transport host test ok" in r.stdout, r.stdout[-4000:]
