@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -166,6 +167,127 @@ int dtp_rccl_destroy(void* h) {
   ncclCommDestroy(t->comm);
   hipStreamDestroy(t->comm_stream);
   delete t;
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Bucket scheduler: the hot-path half of the gradient reducer (parallel/reducer.py keeps planning,
+// hooks and the gloo path).  Buckets are contiguous ranges of the flat gradient arena; a bucket's
+// all-reduce is launched the moment its last parameter reports ready — one call from the backward
+// kernel wrapper, no Python per-bucket work — and finalize() hands the comm stream back to the
+// consumer with a single event.  A parameter counts once per pass (fused layers notify explicitly
+// AND autograd may fire its hook for the same parameter; counting both launched buckets early).
+struct DtpBucket {
+  void* ptr;
+  size_t count;
+  int dtype_kind;
+  int expected, pending;
+  bool launched;
+};
+
+struct DtpReducer {
+  void* transport;
+  std::vector<DtpBucket> buckets;
+  std::vector<std::vector<int>> param_buckets;
+  std::vector<char> ready;
+  bool require_sync = true;
+  unsigned long long passes = 0, launched = 0, duplicate_notifications = 0;
+};
+
+void* dtp_reducer_create(void* transport, int n_buckets, void* const* ptrs, const size_t* counts,
+                         const int* dtype_kinds, int n_params, const int* pb_offsets, const int* pb_indices) {
+  if (!transport || n_buckets <= 0 || n_params <= 0 || !ptrs || !counts || !dtype_kinds || !pb_offsets || !pb_indices)
+    return nullptr;
+  auto* r = new DtpReducer();
+  r->transport = transport;
+  r->buckets.resize(n_buckets);
+  for (int b = 0; b < n_buckets; ++b) {
+    if (!ptrs[b] || counts[b] == 0) { delete r; return nullptr; }
+    r->buckets[b] = DtpBucket{ptrs[b], counts[b], dtype_kinds[b], 0, 0, false};
+  }
+  r->param_buckets.resize(n_params);
+  r->ready.assign(n_params, 0);
+  for (int p = 0; p < n_params; ++p) {
+    for (int k = pb_offsets[p]; k < pb_offsets[p + 1]; ++k) {
+      const int b = pb_indices[k];
+      if (b < 0 || b >= n_buckets) { delete r; return nullptr; }
+      bool dup = false;
+      for (int q : r->param_buckets[p]) dup = dup || q == b;
+      if (dup) continue;
+      r->param_buckets[p].push_back(b);
+      r->buckets[b].expected += 1;
+    }
+  }
+  for (auto& b : r->buckets) {
+    if (b.expected == 0) { delete r; return nullptr; }   // a bucket nobody feeds would never launch
+    b.pending = b.expected;
+  }
+  return r;
+}
+
+// returns the number of buckets launched by this notification (>= 0) or a negative error
+int dtp_reducer_mark_ready(void* h, int param, hipStream_t producer_stream) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r || param < 0 || param >= (int)r->ready.size()) return -2;
+  if (r->ready[param]) { r->duplicate_notifications += 1; return 0; }
+  r->ready[param] = 1;
+  int n = 0;
+  for (int bi : r->param_buckets[param]) {
+    DtpBucket& b = r->buckets[bi];
+    b.pending -= 1;
+    if (b.pending == 0 && r->require_sync && !b.launched) {
+      const int rc = dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream);
+      if (rc != 0) return rc < 0 ? rc : -rc;
+      b.launched = true;
+      r->launched += 1;
+      ++n;
+    }
+  }
+  return n;
+}
+
+// end of a backward pass: launch what never became ready (unused parameters), make the consumer
+// stream wait for every collective, reset for the next pass.  Returns buckets launched here.
+int dtp_reducer_finalize(void* h, hipStream_t stream) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r) return -2;
+  int n = 0;
+  if (r->require_sync) {
+    for (auto& b : r->buckets) {
+      if (b.launched) continue;
+      const int rc = dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, stream);
+      if (rc != 0) return rc < 0 ? rc : -rc;
+      b.launched = true;
+      r->launched += 1;
+      ++n;
+    }
+    const int rc = dtp_rccl_wait(r->transport, stream);
+    if (rc != 0) return rc < 0 ? rc : -rc;
+    r->passes += 1;
+  }
+  for (auto& b : r->buckets) { b.pending = b.expected; b.launched = false; }
+  std::fill(r->ready.begin(), r->ready.end(), 0);
+  return n;
+}
+
+int dtp_reducer_set_sync(void* h, int on) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r) return -2;
+  r->require_sync = on != 0;
+  return 0;
+}
+
+int dtp_reducer_stats(void* h, unsigned long long* passes, unsigned long long* launched,
+                      unsigned long long* duplicates) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r) return -2;
+  *passes = r->passes; *launched = r->launched; *duplicates = r->duplicate_notifications;
+  return 0;
+}
+
+int dtp_reducer_destroy(void* h) {
+  delete static_cast<DtpReducer*>(h);
   return 0;
 }
 

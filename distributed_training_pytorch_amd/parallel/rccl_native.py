@@ -53,6 +53,20 @@ def _rt():
         rt.dtp_rccl_stats.restype = ci
         rt.dtp_rccl_destroy.argtypes = [vp]
         rt.dtp_rccl_destroy.restype = ci
+        ull_p = ctypes.POINTER(ctypes.c_ulonglong)
+        rt.dtp_reducer_create.argtypes = [vp, ci, ctypes.POINTER(vp), ctypes.POINTER(st), ctypes.POINTER(ci), ci,
+                                          ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        rt.dtp_reducer_create.restype = vp
+        rt.dtp_reducer_mark_ready.argtypes = [vp, ci, vp]
+        rt.dtp_reducer_mark_ready.restype = ci
+        rt.dtp_reducer_finalize.argtypes = [vp, vp]
+        rt.dtp_reducer_finalize.restype = ci
+        rt.dtp_reducer_set_sync.argtypes = [vp, ci]
+        rt.dtp_reducer_set_sync.restype = ci
+        rt.dtp_reducer_stats.argtypes = [vp, ull_p, ull_p, ull_p]
+        rt.dtp_reducer_stats.restype = ci
+        rt.dtp_reducer_destroy.argtypes = [vp]
+        rt.dtp_reducer_destroy.restype = ci
         rt._dtp_typed = True
     return rt
 
@@ -107,6 +121,11 @@ class NativeRcclTransport(object):
         if rc != 0:
             raise RuntimeError("dtp_rccl_broadcast failed: %d" % rc)
 
+    def make_scheduler(self, bucket_tensors, param_bucket_lists):
+        """Native bucket scheduler (C++): ``bucket_tensors[b]`` is the flat gradient range of bucket
+        b, ``param_bucket_lists[i]`` the bucket indices parameter i contributes to."""
+        return NativeBucketScheduler(self, bucket_tensors, param_bucket_lists)
+
     def stats(self):
         a, b = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
         self.rt.dtp_rccl_stats(self.handle, ctypes.byref(a), ctypes.byref(b))
@@ -115,6 +134,64 @@ class NativeRcclTransport(object):
     def close(self):
         if getattr(self, "handle", None):
             self.rt.dtp_rccl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeBucketScheduler(object):
+    """Python face of ``dtp_reducer_*`` (csrc/runtime/rccl_transport.cpp): ready-counting, launch
+    of a bucket's all-reduce the moment its last gradient is queued, and the end-of-backward
+    hand-back of the comm stream all happen in C++ — one ctypes call per notification."""
+
+    def __init__(self, transport, bucket_tensors, param_bucket_lists):
+        self.transport = transport
+        self.rt = transport.rt
+        self._keep = list(bucket_tensors)                # the ranges must outlive the scheduler
+        nb, npar = len(bucket_tensors), len(param_bucket_lists)
+        for t in bucket_tensors:
+            if t.dtype not in _KIND or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("bucket ranges must be contiguous CUDA f32/bf16 tensors")
+        ptrs = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in bucket_tensors])
+        counts = (ctypes.c_size_t * nb)(*[t.numel() for t in bucket_tensors])
+        kinds = (ctypes.c_int * nb)(*[_KIND[t.dtype] for t in bucket_tensors])
+        offs, idx = [0], []
+        for lst in param_bucket_lists:
+            idx.extend(int(b) for b in lst)
+            offs.append(len(idx))
+        c_offs = (ctypes.c_int * (npar + 1))(*offs)
+        c_idx = (ctypes.c_int * max(1, len(idx)))(*(idx or [0]))
+        self.handle = self.rt.dtp_reducer_create(transport.handle, nb, ptrs, counts, kinds, npar, c_offs, c_idx)
+        if not self.handle:
+            raise RuntimeError("dtp_reducer_create rejected the bucket plan")
+
+    def mark_ready(self, param_index):
+        n = self.rt.dtp_reducer_mark_ready(self.handle, int(param_index), NativeRcclTransport._stream())
+        if n < 0:
+            raise RuntimeError("dtp_reducer_mark_ready failed: %d" % n)
+        return n
+
+    def finalize(self):
+        n = self.rt.dtp_reducer_finalize(self.handle, NativeRcclTransport._stream())
+        if n < 0:
+            raise RuntimeError("dtp_reducer_finalize failed: %d" % n)
+        return n
+
+    def set_sync(self, on):
+        self.rt.dtp_reducer_set_sync(self.handle, 1 if on else 0)
+
+    def stats(self):
+        a, b, c = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        self.rt.dtp_reducer_stats(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return dict(passes=a.value, launched=b.value, duplicate_notifications=c.value)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.rt.dtp_reducer_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -133,7 +133,8 @@ class BucketedReducer(object):
         if split_large_mb is None:
             split_large_mb = 128.0 if on_gpu else 0.0
         self.reduce_dtype = reduce_dtype
-        self.require_sync = True
+        self._core = None            # native bucket scheduler (C++), arena mode over the RCCL transport
+        self._require_sync = True
         self.pre_ready = None        # optional fn(p): bring an autograd grad into the arena first
         self._cb_queued = False
         self._hooks = []
@@ -176,6 +177,22 @@ class BucketedReducer(object):
             self._point_grads()
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
+        if (flat_grad is not None and hasattr(self.transport, "make_scheduler")
+                and (reduce_dtype is None or reduce_dtype == flat_grad.dtype)):
+            self._param_index = {id(p): i for i, p in enumerate(self.params)}
+            lists = [[b.index for b in self._param_buckets[id(p)]] for p in self.params]
+            self._core = self.transport.make_scheduler([b.flat for b in self.buckets], lists)
+            self._total_bytes = sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
+
+    @property
+    def require_sync(self):
+        return self._require_sync
+
+    @require_sync.setter
+    def require_sync(self, on):
+        self._require_sync = bool(on)
+        if self._core is not None:
+            self._core.set_sync(on)
 
     # ------------------------------------------------------------------ setup
     def _add_bucket(self, b):
@@ -226,6 +243,9 @@ class BucketedReducer(object):
         self._ready_ids.add(id(p))
         if self.pre_ready is not None:
             self.pre_ready(p)
+        if self._core is not None:       # counting + launch in C++ (one call)
+            self.stats["launched"] += self._core.mark_ready(self._param_index[id(p)])
+            return
         for b in self._param_buckets[id(p)]:
             if self._owns_grads:
                 self._sync_into_bucket(b, p)
@@ -262,6 +282,20 @@ class BucketedReducer(object):
 
     def _finalize(self):
         self._cb_queued = False
+        if self._core is not None:
+            ev0 = ev1 = None
+            if self.require_sync and self.measure_exposed and self.world > 1:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            self.stats["launched"] += self._core.finalize()
+            if self.require_sync:
+                if ev0 is not None:
+                    ev1.record()
+                    self._exposed_pairs.append((ev0, ev1))
+                self.stats["finalized"] += 1
+                self.stats["bytes"] += self._total_bytes
+            self._ready_ids.clear()
+            return
         if self.require_sync:
             for b in self.buckets:      # parameters that produced no gradient this pass
                 if not b.launched:

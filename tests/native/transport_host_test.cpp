@@ -73,6 +73,65 @@ int dtp_rccl_broadcast(void* h, void* buf, size_t count, int dtype_kind, int roo
 int dtp_rccl_sync(void* h);
 int dtp_rccl_stats(void* h, unsigned long long* launched, unsigned long long* bytes);
 int dtp_rccl_destroy(void* h);
+void* dtp_reducer_create(void* transport, int n_buckets, void* const* ptrs, const size_t* counts,
+                         const int* dtype_kinds, int n_params, const int* pb_offsets, const int* pb_indices);
+int dtp_reducer_mark_ready(void* h, int param, hipStream_t producer_stream);
+int dtp_reducer_finalize(void* h, hipStream_t stream);
+int dtp_reducer_set_sync(void* h, int on);
+int dtp_reducer_stats(void* h, unsigned long long* passes, unsigned long long* launched,
+                      unsigned long long* duplicates);
+int dtp_reducer_destroy(void* h);
+}
+
+static int count_calls(const char* prefix) {
+  int n = 0;
+  for (const auto& c : g_log.calls) n += c.rfind(prefix, 0) == 0;
+  return n;
+}
+
+// bucket scheduler: params 0,1 -> bucket 0; param 2 -> buckets 1 and 2 (split); param 3 -> bucket 2
+static void test_scheduler(void* transport, MockStream* compute) {
+  float g[4][32];
+  void* ptrs[3] = {g[0], g[1], g[2]};
+  size_t counts[3] = {32, 16, 16};
+  int kinds[3] = {0, 1, 1};
+  int offs[5] = {0, 1, 2, 4, 5};
+  int idx[5] = {0, 0, 1, 2, 2};
+  assert(dtp_reducer_create(nullptr, 3, ptrs, counts, kinds, 4, offs, idx) == nullptr);
+  int bad_idx[5] = {0, 0, 1, 7, 2};
+  assert(dtp_reducer_create(transport, 3, ptrs, counts, kinds, 4, offs, bad_idx) == nullptr);
+  int starve[5] = {0, 0, 0, 0, 0};                        // buckets 1 and 2 would never launch
+  assert(dtp_reducer_create(transport, 3, ptrs, counts, kinds, 4, offs, starve) == nullptr);
+  void* r = dtp_reducer_create(transport, 3, ptrs, counts, kinds, 4, offs, idx);
+  assert(r);
+  for (int pass = 0; pass < 3; ++pass) {
+    g_log.calls.clear();
+    assert(dtp_reducer_mark_ready(r, 9, compute) == -2);
+    assert(dtp_reducer_mark_ready(r, 1, compute) == 0);     // bucket 0 still waits for param 0
+    assert(dtp_reducer_mark_ready(r, 1, compute) == 0);     // duplicate (explicit notify + autograd hook)
+    assert(dtp_reducer_mark_ready(r, 1, compute) == 0);
+    assert(count_calls("allreduce") == 0);
+    assert(dtp_reducer_mark_ready(r, 2, compute) == 1);     // completes bucket 1; bucket 2 waits for param 3
+    assert(dtp_reducer_mark_ready(r, 0, compute) == 1);     // completes bucket 0
+    assert(dtp_reducer_mark_ready(r, 0, compute) == 0);
+    assert(count_calls("allreduce") == 2);
+    assert(dtp_reducer_finalize(r, compute) == 1);          // param 3 produced no gradient: bucket 2 goes now
+    assert(count_calls("allreduce") == 3);
+    assert(g_log.calls.back() == "wait:1:on:100");          // consumer waits on the comm stream, once
+  }
+  // gradient accumulation: no launches while sync is off, counters still reset per pass
+  assert(dtp_reducer_set_sync(r, 0) == 0);
+  g_log.calls.clear();
+  for (int p = 0; p < 4; ++p) assert(dtp_reducer_mark_ready(r, p, compute) == 0);
+  assert(dtp_reducer_finalize(r, compute) == 0 && count_calls("allreduce") == 0 && count_calls("wait") == 0);
+  assert(dtp_reducer_set_sync(r, 1) == 0);
+  for (int p = 0; p < 4; ++p) dtp_reducer_mark_ready(r, p, compute);
+  assert(count_calls("allreduce") == 3);
+  assert(dtp_reducer_finalize(r, compute) == 0);
+  unsigned long long passes = 0, launched = 0, dups = 0;
+  assert(dtp_reducer_stats(r, &passes, &launched, &dups) == 0);
+  assert(passes == 4 && launched == 12 && dups == 9);
+  assert(dtp_reducer_destroy(r) == 0);
 }
 
 int main() {
@@ -117,6 +176,7 @@ int main() {
   unsigned long long launched = 0, bytes = 0;
   assert(dtp_rccl_stats(t, &launched, &bytes) == 0 && launched == 7000 && bytes == want_bytes);
 
+  test_scheduler(t, &compute);
   g_log.calls.clear();
   assert(dtp_rccl_broadcast(t, buf, 64, 0, 0, &compute) == 0);
   assert(g_log.calls.size() == 5 && g_log.calls[2] == "broadcast:100:64:0" && g_log.calls[4] == "wait:1:on:100");
