@@ -220,7 +220,7 @@ def test_native_rccl_transport_world1_and_reducer_over_it():
     assert red.stats["launched"] == len(red.buckets) and red.stats["finalized"] == 1
     assert red._core is not None                    # bucket counting / launching ran in the C++ scheduler
     cs = red._core.stats()
-    assert cs["passes"] == 1 and cs["launched"] == len(red.buckets) and cs["duplicate_notifications"] > 0
+    assert cs["passes"] == 1 and cs["launched"] == len(red.buckets)
     seen = set()
     for kind, v in trace:
         if kind == "ready":
