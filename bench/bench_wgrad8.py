@@ -25,7 +25,7 @@ def timeit(fn, iters=8):
     return (time.perf_counter() - t0) / iters
 
 
-for (C, Co, HW) in [(256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 14)]:
+for (C, Co, HW) in [(256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 14), (128, 128, 112), (128, 256, 56)]:
     x = torch.randn(N, HW, HW, C, device="cuda").to(BF16)
     dy = (torch.randn(N, HW, HW, Co, device="cuda") * 0.1).to(BF16)
     gw = torch.empty(Co, 9 * C, device="cuda", dtype=BF16)
@@ -33,8 +33,8 @@ for (C, Co, HW) in [(256, 256, 56), (256, 512, 28), (512, 512, 28), (512, 512, 1
     ksteps = (N * HW * HW + 63) // 64
     _, nsplit = k.pick_wgrad(Co, C, 9, ksteps)
     rec = dict(shape="%dx%d@%d" % (C, Co, HW), batch=N, nsplit=nsplit)
-    for cfg in (0, 5):
-        for sp in sorted(set([nsplit, max(1, nsplit // 2)])):
+    for cfg in ((0, 6) if C >= 256 else (1, 7)):
+        for sp in (nsplit,):
             k._overrides["wgrad"] = lambda M, Cc, taps, ks, cfg=cfg, sp=sp: (cfg, sp)
             try:
                 rec["cfg%d_s%d_tf" % (cfg, sp)] = round(flops / timeit(lambda: k.conv3x3_wgrad(dy, x, gw)) / 1e9)

@@ -20,7 +20,8 @@ N_CU = 256
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256),
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
-WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 256)}
+WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 256),
+               6: (256, 256), 7: (128, 128)}   # 5: 8-phase port, 6/7: software-pipelined fragment reads
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
 
@@ -78,7 +79,7 @@ def pick_wgrad(M, C, taps, ksteps):
         return _overrides["wgrad"](M, C, taps, ksteps)
     if taps == 9:
         if M >= 256 and C % 256 == 0:
-            cfg = 0
+            cfg = 6          # 256x256 with software-pipelined fragment reads: +0-9 % over cfg 0
         elif M >= 128 and C % 128 == 0:
             cfg = 1
         elif M >= 128:
