@@ -16,6 +16,7 @@ Fusion contracts:
     (overwrite-on-first-write), the reducer is notified per parameter.
 """
 import itertools
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,18 @@ from . import kernels as K
 
 BF16 = torch.bfloat16
 _seed_counter = itertools.count(1)
+
+# run each conv layer's weight gradient on a side stream, concurrently with its data gradient
+OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(key)
+    if s is None:
+        s = _side_streams[key] = torch.cuda.Stream(device=device)
+    return s
 
 
 def _arena_of(layer):
@@ -82,16 +95,28 @@ class _Conv3x3Fn(torch.autograd.Function):
         if layer.relu and not layer.grad_premasked:
             dy = K.relu_mask(dy, y)
         Co = weight.shape[0]
-        K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        if side is not None:
+            # weight gradient on a second stream, concurrent with the data gradient below: both
+            # read dY, neither reads the other's output, and the tail of one kernel's last round of
+            # tiles (conv5: 196 tiles on 256 CUs) is filled by the other's workgroups
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        else:
+            K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         if ctx.has_bias:
             K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
-            arena.notify_grad_ready(bias)
-        arena.notify_grad_ready(weight)
         dx = None
         if ctx.needs_input_grad[0]:
             Ci = weight.shape[1]
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)    # join before anyone consumes the gradient
+        if ctx.has_bias:
+            arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
         return dx, None, None, None
 
 
@@ -116,14 +141,22 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         N, H, W, _ = x.shape
         Co, Ci = weight.shape[0], weight.shape[1]
         dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
-        K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+        else:
+            K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
-        arena.notify_grad_ready(bias)
-        arena.notify_grad_ready(weight)
         dx = None
         if ctx.needs_input_grad[0]:
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
         return dx, None, None, None
 
 
@@ -346,14 +379,22 @@ class _LinearFn(torch.autograd.Function):
         if (layer.relu or layer.drop_p > 0) and not layer.grad_premasked:
             scale = 1.0 / (1.0 - layer.drop_p) if (layer.drop_p > 0 and layer.training) else 1.0
             dy = K.relu_mask(dy, y, scale)
-        K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
+        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
+        else:
+            K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
         K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
-        arena.notify_grad_ready(bias)
-        arena.notify_grad_ready(weight)
         dx = None
         if ctx.needs_input_grad[0]:
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
         return dx, None, None, None, None, None, None
 
 
