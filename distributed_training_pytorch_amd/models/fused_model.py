@@ -89,4 +89,37 @@ class FusedModel(nn.Module):
     def prepare_input(self, x):
         if x.is_cuda and self.param_arena is not None:
             self.param_arena.refresh_lp()
+            if self.training and torch.is_grad_enabled():
+                self._prefetch_derived(x.device)
         return x
+
+    def _prefetch_derived(self, device):
+        """Build the per-step derived weight layouts (dgrad-order conv filters, W^T of the linear
+        layers: ~15 small transposes) on a side stream while the forward pass runs, instead of
+        lazily inside backward on the critical path."""
+        arena = self.param_arena
+        if getattr(self, "_derived_epoch", None) == arena.lp_epoch:
+            return
+        self._derived_epoch = arena.lp_epoch
+        from ..ops import layers as L
+        if not L.OVERLAP_WGRAD:
+            return
+        side = L._side_stream(device)
+        side.wait_stream(torch.cuda.current_stream())
+        first = True
+        with torch.cuda.stream(side):
+            for m in self.modules():
+                if isinstance(m, FusedLayer):
+                    for key, builder in m.derived_builders(needs_input_grad=not first):
+                        m._cached(key, builder)
+                    first = False if any(True for _ in m.parameters(recurse=False)) else first
+            ev = torch.cuda.Event()
+            ev.record(side)
+        arena.derived_event = ev       # the first backward function that needs a layout waits on it
+
+    def finish_forward(self, y):
+        """Optional: join the side stream of ``_prefetch_derived`` at the end of forward (the
+        backward functions wait on its event themselves, see ``ParamArena.wait_derived``)."""
+        if y.is_cuda and self.param_arena is not None:
+            self.param_arena.wait_derived()
+        return y

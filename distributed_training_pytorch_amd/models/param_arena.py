@@ -188,6 +188,15 @@ class ParamArena(object):
                     view.copy_(p.grad)
                     p.grad = view
 
+    def wait_derived(self):
+        """Backward functions call this before touching a derived weight layout: if FusedModel
+        queued their construction on a side stream during forward, make the current stream wait
+        for it (no-op otherwise, and after the first call of a pass)."""
+        ev = getattr(self, "derived_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.derived_event = None
+
     def memory_bytes(self):
         n = self.flat_master.numel() * 4 + self.flat_grad.numel() * self.flat_grad.element_size()
         if self.flat_lp is not None:

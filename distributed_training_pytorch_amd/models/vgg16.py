@@ -123,7 +123,7 @@ class VGG16(FusedModel):
         x = self.avgpool(x)
         x = self.linear1(x)      # + ReLU + dropout fused
         x = self.linear2(x)
-        return self.linear3(x)
+        return self.finish_forward(self.linear3(x))
 
 
 def vgg16_bn(in_channels=3, out_channels=1, **kw):

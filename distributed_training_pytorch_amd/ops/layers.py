@@ -63,6 +63,11 @@ class FusedLayer(nn.Module):
         for p in self.parameters(recurse=False):
             arena.kernel_written.add(id(p))
 
+    def derived_builders(self, needs_input_grad=True):
+        """(key, builder) pairs of the weight layouts this layer derives once per optimizer step
+        for its backward pass; FusedModel builds them on a side stream during forward."""
+        return []
+
     def _cached(self, key, builder):
         arena = _arena_of(self)
         if self._derived_epoch != arena.lp_epoch:
@@ -110,6 +115,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             Ci = weight.shape[1]
+            arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
         if side is not None:
@@ -151,6 +157,7 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
         dx = None
         if ctx.needs_input_grad[0]:
+            arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
         if side is not None:
@@ -171,7 +178,16 @@ def conv_relu_pool(conv, x):
     return _Conv3x3ReluPoolFn.apply(x, conv.weight, conv.bias, conv)
 
 
-class Conv3x3(FusedLayer):
+class _Conv3x3Derived(object):
+    def derived_builders(self, needs_input_grad=True):
+        if not needs_input_grad:
+            return []
+        arena = _arena_of(self)
+        Co, Ci = self.out_channels, self.in_channels
+        return [("wd", lambda: K.conv_weight_to_dgrad(arena.lp(self.weight), Co, Ci))]
+
+
+class Conv3x3(_Conv3x3Derived, FusedLayer):
     """3x3, stride 1, pad 1 convolution (+bias, +ReLU fused).  ``weight`` keeps torch's logical
     ``[Cout, Cin, 3, 3]`` shape (checkpoint compatibility with reference model/vgg16.py:9,12)."""
 
@@ -389,6 +405,7 @@ class _LinearFn(torch.autograd.Function):
         K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
         dx = None
         if ctx.needs_input_grad[0]:
+            arena.wait_derived()
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
         if side is not None:
@@ -398,7 +415,15 @@ class _LinearFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
-class Linear(FusedLayer):
+class _LinearDerived(object):
+    def derived_builders(self, needs_input_grad=True):
+        if not needs_input_grad:
+            return []
+        arena = _arena_of(self)
+        return [("wt", lambda: K.linear_weight_transpose(arena.lp(self.weight)))]
+
+
+class Linear(_LinearDerived, FusedLayer):
     """Linear (+bias) with optional fused ReLU and dropout epilogue (order: linear, relu, dropout —
     reference model/vgg16.py:71-76).  ``out_fp32`` for the logits layer."""
 
