@@ -89,6 +89,8 @@ class FusedModel(nn.Module):
     def prepare_input(self, x):
         if x.is_cuda and self.param_arena is not None:
             self.param_arena.refresh_lp()
+            from ..ops import layers as L
+            L._pending_join.clear()          # a backward pass that raised must not block future joins
             if self.training and torch.is_grad_enabled():
                 self._prefetch_derived(x.device)
         return x

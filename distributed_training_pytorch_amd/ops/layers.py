@@ -30,6 +30,33 @@ _seed_counter = itertools.count(1)
 # run each conv layer's weight gradient on a side stream, concurrently with its data gradient
 OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
 _side_streams = {}
+DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "1") == "1"
+
+
+_pending_join = {}
+
+
+def _fork_wgrad(arena, device, *tensors):
+    """Side stream for a weight-gradient kernel, ordered after everything queued so far on the
+    current stream.  Without a gradient reducer the join is deferred to the END of backward (an
+    autograd-engine callback): the chain of weight gradients then runs as its own pipeline next to
+    the data-gradient / pool-backward chain.  The tensors the kernel reads are handed to the
+    caching allocator with ``record_stream`` so that they are not recycled under it."""
+    side = _side_stream(device)
+    side.wait_stream(torch.cuda.current_stream())
+    deferred = DEFER_JOIN and (arena.reducer is None or getattr(arena.reducer, "world", 1) == 1)
+    if deferred:
+        for t in tensors:
+            t.record_stream(side)
+        key = id(side)
+        if key not in _pending_join:
+            _pending_join[key] = side
+
+            def _join(side=side, key=key):
+                _pending_join.pop(key, None)
+                torch.cuda.current_stream().wait_stream(side)
+            torch.autograd.Variable._execution_engine.queue_callback(_join)
+    return side, deferred
 
 
 def _side_stream(device):
@@ -100,12 +127,12 @@ class _Conv3x3Fn(torch.autograd.Function):
         if layer.relu and not layer.grad_premasked:
             dy = K.relu_mask(dy, y)
         Co = weight.shape[0]
-        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
+                          else (None, False))
         if side is not None:
             # weight gradient on a second stream, concurrent with the data gradient below: both
             # read dY, neither reads the other's output, and the tail of one kernel's last round of
             # tiles (conv5: 196 tiles on 256 CUs) is filled by the other's workgroups
-            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         else:
@@ -118,8 +145,8 @@ class _Conv3x3Fn(torch.autograd.Function):
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)    # join before anyone consumes the gradient
+        if side is not None and not deferred:
+            torch.cuda.current_stream().wait_stream(side)    # join before the reducer ships the gradient
         if ctx.has_bias:
             arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
@@ -147,9 +174,9 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         N, H, W, _ = x.shape
         Co, Ci = weight.shape[0], weight.shape[1]
         dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
-        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
+                          else (None, False))
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         else:
@@ -160,7 +187,7 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
-        if side is not None:
+        if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
@@ -395,9 +422,9 @@ class _LinearFn(torch.autograd.Function):
         if (layer.relu or layer.drop_p > 0) and not layer.grad_premasked:
             scale = 1.0 / (1.0 - layer.drop_p) if (layer.drop_p > 0 and layer.training) else 1.0
             dy = K.relu_mask(dy, y, scale)
-        side = _side_stream(dy.device) if (OVERLAP_WGRAD and ctx.needs_input_grad[0]) else None
+        side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
+                          else (None, False))
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
         else:
@@ -408,7 +435,7 @@ class _LinearFn(torch.autograd.Function):
             arena.wait_derived()
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
-        if side is not None:
+        if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
