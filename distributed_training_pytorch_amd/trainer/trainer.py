@@ -29,6 +29,7 @@ import torch
 from ..utils.profiler import trace_range
 from torch.utils.data import DataLoader
 
+from ..data.device_cache import DeviceCachedLoader
 from ..data.prefetch import DevicePrefetcher
 from ..parallel import comm, env as penv
 from ..parallel.data_parallel import DataParallel
@@ -72,7 +73,8 @@ class Trainer(object):
                  reduce_dtype=None,
                  metrics_file=None,
                  seed=0,
-                 use_hip_graph=False):
+                 use_hip_graph=False,
+                 cache_dataset_on_device=False):
         # T1 logging shim (plain method, keyword-friendly; reference :26)
         self.logger = logger
         # T5 rank discovery (reference :48-50) — defaults make `python main.py` work
@@ -117,6 +119,9 @@ class Trainer(object):
         self.meter = ThroughputMeter()
         # capture the whole train step into one hipGraph (engine/graph.py); hooks opt in through
         # self.graphed_step — only single-process runs without gradient accumulation are captured
+        # keep whole (small enough) datasets resident on the GPU and gather batches there
+        # (data/device_cache.py); falls back to the DataLoader when the dataset does not fit
+        self.cache_dataset_on_device = bool(cache_dataset_on_device)
         self.use_hip_graph = bool(use_hip_graph)
         self.graphed_step = None
 
@@ -376,6 +381,9 @@ class Trainer(object):
             sampler = ShardedSampler(len(dataset), self.world_rank, self.world_size, shuffle=True, seed=self.seed)
         else:
             sampler = ShardedSampler(len(dataset), self.world_rank, self.world_size, shuffle=False, pad=False)
+        if (self.cache_dataset_on_device and self.device.type == "cuda" and collate_fn is None
+                and DeviceCachedLoader.fits(dataset, self.device)):
+            return DeviceCachedLoader(dataset, batch_size, sampler, self.device)
         return DataLoader(dataset, batch_size=batch_size, pin_memory=pin_memory, shuffle=False,
                           sampler=sampler, collate_fn=collate_fn, num_workers=self.num_workers,
                           persistent_workers=self.num_workers > 0, drop_last=False)

@@ -41,6 +41,8 @@ def parse_args(argv=None):
     ap.add_argument("--num-workers", type=int, default=0)
     ap.add_argument("--steps", type=int, default=None, help="cap on steps per epoch (smoke runs)")
     ap.add_argument("--no-progress", action="store_true")
+    ap.add_argument("--device-cache", action="store_true",
+                    help="materialise the dataset once on the GPU and gather batches there (fits-in-HBM datasets)")
     ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (1 process)")
     return ap.parse_args(argv)
 
@@ -74,7 +76,7 @@ if __name__ == "__main__":
                              grad_accum_steps=args.grad_accum,
                              num_workers=args.num_workers,
                              max_steps_per_epoch=args.steps,
-                             progress=not args.no_progress, use_hip_graph=args.hip_graph,
+                             progress=not args.no_progress, use_hip_graph=args.hip_graph, cache_dataset_on_device=args.device_cache,
                              metrics_file="%s/metrics.jsonl" % args.save_folder)
 
     trainer.train()

@@ -380,3 +380,24 @@ def test_custom_fused_model_trains_with_fused_optimizer_cpu():
     net2.load_state_dict(net.state_dict())
     with torch.no_grad():
         assert torch.allclose(net2.eval()(x), net.eval()(x), atol=1e-6)
+
+
+def test_device_cached_loader_matches_dataloader_batches():
+    """DeviceCachedLoader (whole dataset resident, device-side gather) yields exactly the batches a
+    DataLoader with the same ShardedSampler yields, epoch after epoch."""
+    from torch.utils.data import DataLoader
+    from distributed_training_pytorch_amd.data.device_cache import DeviceCachedLoader
+    from distributed_training_pytorch_amd.data.synthetic import SyntheticImageDataset
+    ds = SyntheticImageDataset(22, 3, 8, 8, seed=4)
+    for rank in (0, 1):
+        s1 = ShardedSampler(len(ds), rank, 2, shuffle=True, seed=0)
+        s2 = ShardedSampler(len(ds), rank, 2, shuffle=True, seed=0)
+        ref = DataLoader(ds, batch_size=4, sampler=s1)
+        cached = DeviceCachedLoader(ds, 4, s2, "cpu", max_bytes=1 << 30)
+        assert DeviceCachedLoader.fits(ds, "cpu", max_bytes=1 << 30) and not DeviceCachedLoader.fits(ds, "cpu", max_bytes=10)
+        assert len(cached) == len(ref)
+        for epoch in (0, 3):
+            s1.set_epoch(epoch)
+            cached.sampler.set_epoch(epoch)
+            for (xa, ya), (xb, yb) in zip(ref, cached):
+                assert torch.equal(xa, xb) and torch.equal(ya, yb)
