@@ -140,6 +140,7 @@ def main():
                         "the reference publishes no numbers" % STOCK_1GPU_BF16_IMG_S,
             "dtype": "bf16", "data": "synthetic (device-resident f32 NCHW batches, random-init weights)",
             "final_loss": final_loss,
+            "max_memory_reserved_gb": torch.cuda.max_memory_reserved(dev) / 2 ** 30,
             "allreduce_exposed_ms_per_step": exposed,     # compute stream idle waiting for gradient buckets (rank 0)
             "config": {"model": "VGG16 (no BN, %d classes, 134M params)" % args.classes,
                        "global_batch": global_batch, "image_size": args.image_size,

@@ -166,15 +166,25 @@ struct Conv1WgradParams {
   float* partial;         // [gridDim.x][64][32] f32
   const char* zero_page;
   int ntiles;
+  // self-masking (optional): recompute sign(conv1(x) + bias) for the tile from the im2col rows the
+  // kernel builds anyway (one K=32 MFMA step per 16x16 block) and zero dY where the forward ReLU
+  // was inactive.  The consumer's data-gradient kernel then skips its mask read of the 64-channel
+  // full-resolution activation (1.6 GB at batch 256).
+  const bf16_t* mask_w;     // [64][27] bf16 forward weights, or null
+  const float* mask_bias;   // [64] or null
 };
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams p) {
   // LDS: dY image [256 px][64] bf16 (128-B rows, tr-read swizzle) 32 KiB | Xt image [32 k][256 px] rows of 528 B
+  //      | (self-masking) A image [256 px][32] bf16 16 KiB | W image [64][32] bf16 4 KiB
   constexpr int XT_RB = 528;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lD = smem;
   char* lX = smem + 256 * 128;
+  char* lA = lX + 32 * XT_RB;
+  char* lW = lA + 256 * 64;
+  const bool self_mask = p.mask_w != nullptr;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   typedef __attribute__((ext_vector_type(4))) short s4;
@@ -199,6 +209,20 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+  if (self_mask) {   // forward weight image, same layout as conv1_fprop_kernel; lives for the whole kernel
+    const int K = 9 * p.c.Cin;
+    const int row = tid >> 2, ch = tid & 3;
+    u32x4_t qv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k0 = ch * 8 + 2 * e;
+      const uint32_t lo = k0 < K ? p.mask_w[row * K + k0] : 0;
+      const uint32_t hi = k0 + 1 < K ? p.mask_w[row * K + k0 + 1] : 0;
+      qv[e] = lo | (hi << 16);
+    }
+    *(u32x4_t*)(lW + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = qv;
+  }
+
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const long m0 = (long)tile * C1_TILE;
     __syncthreads();   // previous tile fully consumed
@@ -213,8 +237,57 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
       gather_patch<T>(p.c, m0 + tid, v);
 #pragma unroll
       for (int k = 0; k < 27; ++k) *(bf16_t*)(lX + k * XT_RB + tid * 2) = f32_to_bf16(v[k]);
+      if (self_mask) {   // row-major copy [px][32] for the forward recomputation (as in conv1_fprop)
+        const int sw = (tid >> 1) & 3;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          u32x4_t qv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k0 = ch * 8 + 2 * e;
+            qv[e] = pack_bf16x2(k0 < 27 ? v[k0] : 0.f, k0 + 1 < 27 ? v[k0 + 1] : 0.f);
+          }
+          *(u32x4_t*)(lA + tid * 64 + ((ch ^ sw) << 4)) = qv;
+        }
+      }
     }
     __syncthreads();   // (drains the LDS-DMA: vmcnt(0) is emitted before the barrier)
+    if (self_mask) {
+      // y = W * im2col + b for this wave's 64 pixels; zero dY (in its LDS image) where y <= 0.
+      // The wave masks exactly the rows it reads below, so a wave-level fence is enough.
+      const int fr = lane & 15, fk = lane >> 4;
+      const int foff = fr * 64 + ((fk ^ ((fr >> 1) & 3)) << 4);
+      const int cq = fk * 4;
+      bf16x8_t xf[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8_t*)(lA + (wave * 64 + i * 16) * 64 + foff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(lW + (j * 16) * 64 + foff);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.mask_bias ? p.mask_bias[j * 16 + cq + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4_t y = {0.f, 0.f, 0.f, 0.f};
+          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], y, 0, 0, 0);
+          const int pl = wave * 64 + i * 16 + fr;       // pixel (dY image row)
+          const int nl = j * 16 + cq;                   // first of 4 channels
+          const int rsw = (((pl >> 1) & 1) | (((pl >> 3) & 1) << 1)) << 1;
+          u32x2_t* dp = (u32x2_t*)(lD + pl * 128 + ((((nl >> 3)) ^ rsw) << 4) + ((nl >> 2) & 1) * 8);
+          u32x2_t d = *dp;
+          // the forward kernel stores bf16(relu(y + b)): active <=> that bf16 value is > 0
+          const bool a0 = bf16_to_f32(f32_to_bf16(y[0] + bv[0])) > 0.f, a1 = bf16_to_f32(f32_to_bf16(y[1] + bv[1])) > 0.f;
+          const bool a2 = bf16_to_f32(f32_to_bf16(y[2] + bv[2])) > 0.f, a3 = bf16_to_f32(f32_to_bf16(y[3] + bv[3])) > 0.f;
+          d[0] = (a0 ? (d[0] & 0xFFFFu) : 0u) | (a1 ? (d[0] & 0xFFFF0000u) : 0u);
+          d[1] = (a2 ? (d[1] & 0xFFFFu) : 0u) | (a3 ? (d[1] & 0xFFFF0000u) : 0u);
+          *dp = d;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
     // wave: pixels [64*wave, 64*wave+64) -> two 32-deep k-substeps
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -308,15 +381,16 @@ extern "C" int dtp_conv1_fprop(const void* x, int in_kind, const void* w, const 
 extern "C" int dtp_conv1_wgrad(const void* x, int in_kind, const void* dy, void* out_w, void* out_b, float* partial,
                                int max_grid, const void* zero_page, int N, int Cin, int H, int W, float scale,
                                const float* mean, const float* inv_std, int out_fp32, float beta_w, float beta_b,
-                               hipStream_t s) {
+                               const void* mask_w, const float* mask_bias, hipStream_t s) {
   Conv1WgradParams p;
+  p.mask_w = (const bf16_t*)mask_w; p.mask_bias = mask_bias;
   int rc = fill_params(p.c, x, N, Cin, H, W, scale, mean, inv_std);
   if (rc) return rc;
   p.dy = (const char*)dy; p.partial = partial; p.zero_page = (const char*)zero_page;
   p.ntiles = (int)((p.c.M + C1_TILE - 1) / C1_TILE);
   int grid = p.ntiles < max_grid ? p.ntiles : max_grid;
   if (grid < 1) return -12;
-  constexpr int lds = 256 * 128 + 32 * 528;
+  constexpr int lds = 256 * 128 + 32 * 528 + 256 * 64 + 64 * 64;
   if (in_kind == 0) hipLaunchKernelGGL(conv1_wgrad_kernel<float>, dim3(grid), dim3(256), lds, s, p);
   else if (in_kind == 1) hipLaunchKernelGGL(conv1_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, p);
   else if (in_kind == 2) hipLaunchKernelGGL(conv1_wgrad_kernel<uint8_t>, dim3(grid), dim3(256), lds, s, p);

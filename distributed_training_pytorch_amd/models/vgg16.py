@@ -14,12 +14,17 @@ conv kernel.  Values are emitted as contiguous fp32 NCHW tensors, so a stock ``t
 Differences on purpose: ``in_channels`` is honoured (reference ignores it, quirk #22); GPU compute
 is bf16 with f32 accumulation against fp32 master weights held in a flat ``ParamArena``.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, FusedLayer, Linear, MaxPool2x2,
                           ReLUMarker, conv_relu_pool)
 from .fused_model import FusedModel
+
+
+SELF_MASK = os.environ.get("DTP_CONV1_SELF_MASK", "1") == "1"     # A/B switch (see ConvBlock)
 
 
 class BatchNormNHWC(nn.BatchNorm2d):
@@ -42,12 +47,17 @@ class ConvBlock(nn.Module):
             cin = in_channels if i == 0 else out_channels
             fused_relu = not batch_norm
             if first and i == 0:
-                conv = ConvFirst(cin, out_channels, relu=fused_relu, grad_premasked=fused_relu)
+                # conv1_1 masks its own incoming gradient inside its weight-gradient kernel (it
+                # recomputes the forward sign from the image), so conv1_2's data-gradient does not
+                # read the 64-channel full-resolution activation as a mask
+                conv = ConvFirst(cin, out_channels, relu=fused_relu, grad_premasked=fused_relu and not SELF_MASK,
+                                 self_mask=fused_relu and SELF_MASK)
             else:
                 # the input of a block's first conv is a pool output: its mask is applied by the
                 # pool backward, so only convs fed directly by a fused conv+ReLU mask their dgrad
                 conv = Conv3x3(cin, out_channels, relu=fused_relu,
-                               input_is_relu_out=(i > 0 and fused_relu), grad_premasked=fused_relu)
+                               input_is_relu_out=(i > 0 and fused_relu and not (first and SELF_MASK)),
+                               grad_premasked=fused_relu)
             layers.append(conv)
             if batch_norm:
                 layers.append(BatchNormNHWC(out_channels))

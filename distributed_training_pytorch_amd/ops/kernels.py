@@ -525,8 +525,11 @@ def conv1_fprop(x, w, bias, relu=True, scale=1.0, mean=None, inv_std=None):
     return y
 
 
-def conv1_wgrad(x, dy, out_w, out_b, beta_w=0.0, beta_b=0.0, scale=1.0, mean=None, inv_std=None):
-    """out_w[64, 27] and out_b[64] (same dtype, f32 or bf16) from dy NHWC bf16 [N,H,W,64] and the raw input."""
+def conv1_wgrad(x, dy, out_w, out_b, beta_w=0.0, beta_b=0.0, scale=1.0, mean=None, inv_std=None,
+                mask_w=None, mask_bias=None):
+    """out_w[64, 27] and out_b[64] (same dtype, f32 or bf16) from dy NHWC bf16 [N,H,W,64] and the raw input.
+    ``mask_w`` ([64, 27] bf16 forward weights, + ``mask_bias``): dy is NOT yet masked by this layer's
+    ReLU; the kernel recomputes the forward sign per tile and masks dy itself."""
     if x.dtype not in _IN_KINDS or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
         raise ValueError("conv1_wgrad: bad x")
     _need(dy, BF16, "dy")
@@ -535,12 +538,19 @@ def conv1_wgrad(x, dy, out_w, out_b, beta_w=0.0, beta_b=0.0, scale=1.0, mean=Non
         raise ValueError("conv1_wgrad: bad shapes")
     if out_w.dtype != out_b.dtype or out_w.dtype not in (torch.float32, BF16):
         raise ValueError("conv1_wgrad: bad output dtype")
+    if mask_w is not None:
+        _need(mask_w, BF16, "mask_w")
+        if mask_w.numel() != 64 * 27:
+            raise ValueError("conv1_wgrad: mask_w must be the [64, 27] forward weights")
+        if mask_bias is not None:
+            _need(mask_bias, torch.float32, "mask_bias")
     max_grid = 3 * N_CU
     partial = workspace.get("conv1_partial", max_grid * 2048, torch.float32, x.device)
     rc = _lib.hip().dtp_conv1_wgrad(ptr(x), _IN_KINDS[x.dtype], ptr(dy), ptr(out_w), ptr(out_b), ptr(partial),
                                     max_grid, ptr(workspace.zero_page(x.device)), N, Cin, H, W, float(scale),
                                     ptr(mean), ptr(inv_std), int(out_w.dtype == torch.float32), float(beta_w),
-                                    float(beta_b), stream())
+                                    float(beta_b), ptr(mask_w), ptr(mask_bias) if mask_w is not None else None,
+                                    stream())
     check(rc, "conv1_wgrad")
 
 

@@ -30,7 +30,12 @@ _seed_counter = itertools.count(1)
 # run each conv layer's weight gradient on a side stream, concurrently with its data gradient
 OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
 _side_streams = {}
-DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "1") == "1"
+# Deferred join (join the side stream only at the end of backward) is OFF by default: it needs
+# record_stream() on every activation the weight-gradient kernels read, which parks those blocks in
+# the caching allocator until the side stream's events retire — with the host running steps ahead
+# the reserved memory grew from 14 GB to 140-235 GB at batch 256 and one run in ~12 hit the limit
+# and ran 5x slower (allocator free/sync storm).  The per-layer join needs no record_stream.
+DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "0") == "1"
 
 
 _pending_join = {}
@@ -267,12 +272,17 @@ class _ConvFirstFn(torch.autograd.Function):
         arena = _arena_of(layer)
         xp, y, weight, bias = ctx.saved_tensors
         dy = dy.contiguous()
-        if layer.relu and not layer.grad_premasked:
+        in_kernel_mask = ctx.fast and layer.relu and layer.self_mask and not layer.grad_premasked
+        if layer.relu and not layer.grad_premasked and not in_kernel_mask:
             dy = K.relu_mask(dy, y)
         Co, Ci = weight.shape[0], weight.shape[1]
         if ctx.fast:
+            # self_mask: the weight-gradient kernel recomputes sign(conv1(x)+b) per tile and masks dy
+            # itself, so the layer above skipped the 64-channel mask read in its data-gradient
             K.conv1_wgrad(xp, dy, arena.grad(weight), arena.grad(bias), arena.grad_beta(weight),
-                          arena.grad_beta(bias), layer.in_scale, layer.in_mean, layer.in_inv_std)
+                          arena.grad_beta(bias), layer.in_scale, layer.in_mean, layer.in_inv_std,
+                          mask_w=arena.lp(weight) if in_kernel_mask else None,
+                          mask_bias=bias.detach() if in_kernel_mask else None)
         else:
             gpad = K.workspace.get("convfirst_gw", Co * 9 * layer.c_pad, torch.float32, dy.device)
             gpad = gpad[:Co * 9 * layer.c_pad].view(Co, 9 * layer.c_pad)
@@ -290,11 +300,12 @@ class _ConvFirstFn(torch.autograd.Function):
 
 
 class ConvFirst(FusedLayer):
-    def __init__(self, in_channels, out_channels, relu=True, grad_premasked=False, c_pad=64):
+    def __init__(self, in_channels, out_channels, relu=True, grad_premasked=False, c_pad=64, self_mask=False):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.relu = relu
         self.grad_premasked = grad_premasked
+        self.self_mask = bool(self_mask)      # ReLU backward applied inside this layer's own wgrad kernel
         self.c_pad = c_pad
         self.in_scale, self.in_mean, self.in_inv_std = 1.0, None, None
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))

@@ -385,6 +385,15 @@ def test_conv1_fprop_wgrad(shape, in_dtype):
         k.conv1_wgrad(x, dy, gw, gb, beta_w=1.0, beta_b=1.0, **kw)
         _close(gw, 2 * gref, 3e-2, 3e-2 * gref.abs().max().item(), "conv1 wgrad acc")
         _close(gb, 2 * bref, 3e-2, 3e-2 * bref.abs().max().item(), "conv1 bgrad acc")
+    # self-masking: the kernel recomputes sign(conv1(x)+b) and masks dy itself == feeding it the
+    # pre-masked dy (mask from the forward kernel's own bf16 output), bit for bit
+    dym = (dy.float() * (y.float() > 0)).to(BF16)
+    g1, b1 = torch.empty(64, 27, device="cuda"), torch.empty(64, device="cuda")
+    g2, b2 = torch.empty(64, 27, device="cuda"), torch.empty(64, device="cuda")
+    k.conv1_wgrad(x, dym, g1, b1, **kw)
+    k.conv1_wgrad(x, dy, g2, b2, mask_w=w, mask_bias=b, **kw)
+    assert torch.equal(g1, g2) and torch.equal(b1, b2)
+    assert not torch.equal(g1, gw.float()) or (y.float() > 0).all()
 
 
 @pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (3, 9, 11, 64, 256), (2, 56, 56, 256, 256)])
