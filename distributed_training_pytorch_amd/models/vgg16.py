@@ -19,8 +19,8 @@ import os
 import torch
 import torch.nn as nn
 
-from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, FusedLayer, Linear, MaxPool2x2,
-                          ReLUMarker, conv_relu_pool)
+from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, Linear, MaxPool2x2, ReLUMarker,
+                          conv_relu_pool)
 from .fused_model import FusedModel
 
 

@@ -13,7 +13,6 @@ import ctypes
 import weakref
 
 import torch
-import torch.distributed as dist
 
 from .. import _lib
 from . import comm
