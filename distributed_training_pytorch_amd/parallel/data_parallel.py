@@ -51,23 +51,42 @@ class DataParallel(nn.Module):
         want = os.environ.get("DTP_TRANSPORT", "auto").lower()
         if device.type != "cuda" or not comm.is_dist() or comm.world_size() == 1 or want == "torch":
             return TorchPGTransport()
-        native, ok = None, 1.0
-        try:
-            from .rccl_native import NativeRcclTransport
-            native = NativeRcclTransport()
-            probe = torch.full((256,), float(comm.rank() + 1), device=device)
-            native.wait(native.launch(probe), probe)
-            torch.cuda.current_stream().synchronize()
-            expect = (comm.world_size() + 1) / 2.0            # mean of 1..world
-            if not bool(((probe - expect).abs() < 1e-5).all()):
-                ok = 0.0
-        except Exception:
-            ok = 0.0
+        # The set-up runs in a watchdog thread: a communicator that never comes up (a rank stuck in
+        # ncclCommInitRank or in the probe collective) must degrade to the process-group transport
+        # after DTP_NATIVE_INIT_TIMEOUT_S seconds instead of hanging the job.
+        import threading
+        box = dict(native=None, ok=0.0)
+
+        def _bring_up():
+            try:
+                torch.cuda.set_device(device)                 # current device is per thread
+                from .rccl_native import NativeRcclTransport
+                box["native"] = NativeRcclTransport(device=device.index if device.index is not None
+                                                    else torch.cuda.current_device())
+                probe = torch.full((256,), float(comm.rank() + 1), device=device)
+                box["native"].wait(box["native"].launch(probe), probe)
+                torch.cuda.current_stream().synchronize()
+                expect = (comm.world_size() + 1) / 2.0        # mean of 1..world
+                box["ok"] = 1.0 if bool(((probe - expect).abs() < 1e-5).all()) else 0.0
+            except Exception:
+                box["ok"] = 0.0
+
+        th = threading.Thread(target=_bring_up, name="dtp-native-rccl-init", daemon=True)
+        th.start()
+        th.join(float(os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", "120")))
+        timed_out = th.is_alive()
+        native, ok = (None, 0.0) if timed_out else (box["native"], box["ok"])
         agreed = comm.all_reduce_scalars([ok], op="min")[0]
         if agreed >= 1.0:
             return native
         if native is not None:
             native.close()
+        if comm.rank() == 0:
+            import warnings
+            warnings.warn("native RCCL transport unavailable (%s on at least one rank); gradients go through the "
+                          "torch.distributed process group" % ("bring-up timed out" if timed_out else
+                                                               "bring-up or self-check failed" if ok < 1.0 else
+                                                               "another rank failed"))
         if want == "native":
             raise RuntimeError("DTP_TRANSPORT=native but the RCCL transport did not come up on every rank")
         return TorchPGTransport()

@@ -432,15 +432,20 @@ def test_uint8_ingest_matches_float_input_on_gpu():
     assert cos > 0.99, cos
 
 
-def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path):
+@pytest.mark.parametrize("transport", ["torch", "auto"])
+def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport):
     """Multi-process GPU path on a one-GPU box: two ranks share cuda:0, process group over gloo,
     a small user-defined FusedModel, six optimizer steps; gradients and parameters must be
-    identical across ranks after every all-reduce (tests/dist_worker.py::scenario_gpu_shared)."""
+    identical across ranks after every all-reduce (tests/dist_worker.py::scenario_gpu_shared).
+    ``auto``: RCCL cannot build a communicator over a duplicated GPU, so the native bring-up must
+    fail or run into its watchdog deadline and every rank must agree on the process-group
+    transport instead of hanging."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DTP_TRANSPORT="torch", OMP_NUM_THREADS="2", DTP_PG_TIMEOUT_S="60")
+    env = dict(os.environ, DTP_TRANSPORT=transport, DTP_NATIVE_INIT_TIMEOUT_S="15", OMP_NUM_THREADS="2",
+               DTP_PG_TIMEOUT_S="60")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(29750 + os.getpid() % 100),
            os.path.join(root, "tests", "dist_worker.py"), "gpu_shared", str(tmp_path)]
