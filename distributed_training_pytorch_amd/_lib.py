@@ -24,13 +24,13 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
                                                      ctypes.c_size_t, ctypes.c_long, ctypes.c_ulonglong)
 
 _SIGS = {
-    "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],
-    "dtp_conv_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+    "dtp_conv_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                      c_float, c_void_p],
     "dtp_wgrad_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],

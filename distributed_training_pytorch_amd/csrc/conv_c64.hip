@@ -26,6 +26,7 @@ struct ConvC64Params {
   const float* bias;     // [O] or null
   const char* mask_src;  // [N*H*W][O] bf16 or null
   char* out;             // [N*H*W][O] bf16   (POOL: [N*(H/2)*(W/2)][O], the 2x2-max-pooled output)
+  unsigned char* bits_out;   // optional (non-POOL): (output > 0), byte (px*O + c)/8, bit c%8 — ReLU mask for a later dgrad
   uint32_t* codes;       // POOL: [N*(H/2)*(W/2)][O/8] 4-bit (first-argmax, max > 0) codes for the pool backward
   const char* zero_page;
   int N, H, W;
@@ -252,6 +253,16 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
             }
           }
           *(u32x4_t*)(p.out + goff) = v;
+          if (p.bits_out) {
+            uint32_t b = 0;
+  #pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t vw = v[e];
+              b |= (uint32_t)(((vw & 0x8000u) == 0) && ((vw & 0x7FFFu) != 0)) << (2 * e);
+              b |= (uint32_t)(((vw & 0x80000000u) == 0) && ((vw & 0x7FFF0000u) != 0)) << (2 * e + 1);
+            }
+            p.bits_out[goff >> 4] = (unsigned char)b;
+          }
         }
       }
     }
@@ -263,8 +274,8 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 // X [N,H,W,64] bf16, Wt [O][576] bf16 -> out [N,H,W,O] bf16 (O = 64 or 128)
 // codes != null: fused ReLU + 2x2 max-pool epilogue; out is then [N,H/2,W/2,O] and codes [N,H/2,W/2,O/8] uint32
 extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, const void* mask_src, void* out,
-                            void* codes, const void* zero_page, int N, int H, int W, int O, int relu, float mask_scale,
-                            hipStream_t stream) {
+                            void* codes, void* bits_out, const void* zero_page, int N, int H, int W, int O, int relu,
+                            float mask_scale, hipStream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || (O != 64 && O != 128)) return -10;
   ConvC64Params p;
   p.X = (const char*)X; p.Wt = (const char*)Wt; p.bias = bias; p.mask_src = (const char*)mask_src;
@@ -282,6 +293,8 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
   const long grid = units * p.RC;
   if (grid > 0x7FFFFFFFL) return -11;
   p.codes = (uint32_t*)codes;
+  p.bits_out = (unsigned char*)bits_out;
+  if (codes && bits_out) return -13;     // the pool codes already carry the sign bit
   if (codes) {   // fused ReLU + max-pool: windows must not straddle row chunks or the image edge
     if ((H & 1) || (W & 1) || !relu || mask_src) return -12;
     if (p.rows_per_chunk & 1) {

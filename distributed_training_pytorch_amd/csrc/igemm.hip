@@ -30,6 +30,8 @@ struct IgemmParams {
   const char* B;
   const float* bias;
   const char* mask_src;   // bf16 [M][ldo]: output is multiplied by (mask_src > 0) * mask_scale
+  const unsigned char* mask_bits;   // the same mask as 1 bit per element (byte (m*ldo+n)/8, bit n%8); wins over mask_src
+  unsigned char* bits_out;          // optional: (final bf16 output > 0) in that layout (ReLU mask for a later dgrad)
   char* out;              // bf16 or f32 [M][ldo]
   float* partial;         // split-K slabs [z][M][Ncols] f32 (when gridDim.y > 1)
   float* colsum_part;     // optional [tiles_m][Ncols] f32: column sums of the final bf16 output tile
@@ -281,15 +283,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   //   RAW  every slot is read >= 1 phase after the vmcnt that retires its DMA (+ a barrier);
   //   WAR  every slot is re-staged >= 2 phases after its last ds_read (covers the stagger).
   if constexpr (PIPE == 2) {
-    static_assert(BM == 256 && BN == 256 && WGM == 2 && WGN == 4 || PIPE != 2, "8-phase needs the 256x256 2x4 tile");
-    constexpr int SLOT = 16384;
+    // Two instances: 256x256 as 2x4 waves and 512x128 as 4x2 waves (outputs of <= 128 channels);
+    // both give every wave a 128x64 tile, the smallest whose LDS fragment traffic (24 KB per 64
+    // MFMAs) stays under the matrix pipe's time.
+    static_assert(WGM * WGN == 8 && BM == WGM * 128 && BN == WGN * 64, "8-phase: 8 waves of 128x64 each");
+    constexpr int NA = WGM;               // global_load_lds per lane for an A half-tile (64 rows a pass)
+    constexpr int NB = WGN / 2;           // ... for a B half-tile
+    constexpr int SA = WGM * 8192;        // A half-tile slot: 64 rows per wave row
+    constexpr int SB = WGN * 4096;        // B half-tile slot: 32 rows per wave column
+    constexpr int DB = 2 * SA + 2 * SB;   // one K-tile: [A0, A1, B0, B1]
+    constexpr int VMC = 2 * (NA + NB);    // the 4 youngest half-tile issues (2 A + 2 B) may stay in flight
+    const int grp = wm * 2 / WGM;         // stagger group: upper / lower half of the wave rows
     // B half-tile staging pointers: LDS row rho = 64*j + srow  <->  tile row ((rho>>5)<<6) + h*32 + (rho&31)
-    const char* bp8[2][2];
-    bool bk8[2][2];
+    const char* bp8[2][NB];
+    bool bk8[2][NB];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NB; ++j) {
         const int rho = 64 * j + srow;
         const int n = n0 + ((rho >> 5) << 6) + h * 32 + (rho & 31);
         bk8[h][j] = n < p.Ncols;
@@ -314,9 +325,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int tap; long ka, kb;
       koffs(T, tap, ka, kb);
       const bool live = T < kend;
-      char* dst = smem + (d * 4 + h) * SLOT + wave * 1024;
+      char* dst = smem + d * DB + h * SA + wave * 1024;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NA; ++j) {
         const bool ok = live && ((amask[2 * j + h] >> tap) & 1u);
         const char* g = ok ? aptr[2 * j + h] + ka : p.zero_page;
         glds16(g, dst + j * 8192);
@@ -327,9 +338,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int tap; long ka, kb;
       koffs(T, tap, ka, kb);
       const bool live = T < kend;
-      char* dst = smem + (d * 4 + 2 + h) * SLOT + wave * 1024;
+      char* dst = smem + d * DB + 2 * SA + h * SB + wave * 1024;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NB; ++j) {
         const char* g = (live && bk8[h][j]) ? bp8[h][j] + kb : p.zero_page;
         glds16(g, dst + j * 8192);
       }
@@ -339,13 +350,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     bf16x8_t xa[2][4], b0f[2][2], b1f[2][2];
 #define DTP_READ_A(h, d)                                                                              \
   {                                                                                                   \
-    const char* s_ = smem + ((d) * 4 + (h)) * SLOT + (wm * 64) * 128;                                 \
+    const char* s_ = smem + (d) * DB + (h) * SA + (wm * 64) * 128;                                       \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)    \
         xa[ks][i] = *(const bf16x8_t*)(s_ + i * 2048 + (ks ? foff1 : foff0));                         \
   }
 #define DTP_READ_B(h, d, dst)                                                                         \
   {                                                                                                   \
-    const char* s_ = smem + ((d) * 4 + 2 + (h)) * SLOT + (wn * 32) * 128;                             \
+    const char* s_ = smem + (d) * DB + 2 * SA + (h) * SB + (wn * 32) * 128;                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
         dst[ks][j] = *(const bf16x8_t*)(s_ + j * 2048 + (ks ? foff1 : foff0));                        \
   }
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 #define DTP_PHASE_SYNC_IN()                                   \
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");  \
   __builtin_amdgcn_s_barrier();                               \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
   __builtin_amdgcn_sched_barrier(0);                          \
@@ -374,9 +385,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     issue_A(I1{}, I0{}, kbeg);
     issue_B(I0{}, I1{}, kbeg + 1);
     issue_A(I0{}, I1{}, kbeg + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VMC) : "memory");
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();     // stagger the second wave row by one barrier
+    if (grp == 1) __builtin_amdgcn_s_barrier();    // stagger the second group of wave rows by one barrier
     __builtin_amdgcn_sched_barrier(0);
 
     int t = kbeg;
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       issue_A(I0{}, I1{}, t + 3);                             // P8
       DTP_PHASE_SYNC_IN(); DTP_MMA(1, 0, b0f) DTP_PHASE_SYNC_OUT();
     }
-    if (wm == 0) __builtin_amdgcn_s_barrier();     // pair the stagger barrier of the other wave row
+    if (grp == 0) __builtin_amdgcn_s_barrier();    // pair the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain (dummy) DMA before the C image reuses LDS
 #undef DTP_PHASE_SYNC_IN
 #undef DTP_READ_A
@@ -526,7 +537,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       if (m >= p.M || n >= p.Ncols) continue;
       u32x4_t v = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
       const size_t goff = ((size_t)m * p.ldo + n) * 2;
-      if (p.mask_src) {
+      if (p.mask_bits) {
+        const uint32_t mb = p.mask_bits[goff >> 4];       // 8 elements = 16 output bytes per mask byte
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t vw = v[e];
+          float lo = ((mb >> (2 * e)) & 1u) ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+          float hi = ((mb >> (2 * e + 1)) & 1u) ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+          v[e] = pack_bf16x2(lo, hi);
+        }
+      } else if (p.mask_src) {
         const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -540,6 +560,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         }
       }
       *(u32x4_t*)(p.out + goff) = v;
+      if (p.bits_out) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t vw = v[e];
+          b |= (uint32_t)(((vw & 0x8000u) == 0) && ((vw & 0x7FFFu) != 0)) << (2 * e);
+          b |= (uint32_t)(((vw & 0x80000000u) == 0) && ((vw & 0x7FFF0000u) != 0)) << (2 * e + 1);
+        }
+        p.bits_out[goff >> 4] = (unsigned char)b;
+      }
       if (p.colsum_part) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -613,7 +643,8 @@ static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   return DTP_CHECK_LAUNCH();
 }
 
-extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, const void* mask_src, void* out,
+extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, const void* mask_src,
+                            const void* mask_bits, void* bits_out, void* out,
                             float* partial, float* colsum_part, const void* zero_page, int M, int Ncols, int C,
                             int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
@@ -630,6 +661,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.A = (const char*)A; p.B = (const char*)B; p.bias = bias; p.mask_src = (const char*)mask_src;
   p.out = (char*)out; p.partial = partial; p.zero_page = (const char*)zero_page;
   p.colsum_part = colsum_part;
+  p.mask_bits = (const unsigned char*)mask_bits; p.bits_out = (unsigned char*)bits_out;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
   p.seed_ptr = (const unsigned long long*)seed_ptr;
@@ -644,6 +676,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   nsplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
   if (nsplit > 1 && partial == nullptr) return -15;
   if (colsum_part && (nsplit > 1 || out_fp32)) return -17;   // only the bf16 C-image epilogue emits it
+  if ((mask_bits || bits_out) && (nsplit > 1 || out_fp32)) return -20;   // 1-bit masks: same epilogue only
   int rc;
   const bool t9 = taps == 9;
 #define DTP_IG(BM_, BN_, WGM_, WGN_, PIPE_)                                     \
@@ -669,6 +702,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 11: rc = DTP_IG(128, 128, 2, 2, 1); break;
     case 12: rc = DTP_IG(128, 64, 2, 1, 1); break;
     case 16: rc = DTP_IG(256, 256, 2, 4, 2); break;   // 8-phase, counted vmcnt
+    case 17: rc = DTP_IG(512, 128, 4, 2, 2); break;   // 8-phase for outputs of <= 128 channels
     default: return -16;
   }
 #undef DTP_IG

@@ -57,7 +57,10 @@ class ConvBlock(nn.Module):
                 # pool backward, so only convs fed directly by a fused conv+ReLU mask their dgrad
                 conv = Conv3x3(cin, out_channels, relu=fused_relu,
                                input_is_relu_out=(i > 0 and fused_relu and not (first and SELF_MASK)),
-                               grad_premasked=fused_relu)
+                               grad_premasked=fused_relu,
+                               # 1-bit (y > 0) masks for the next conv's data gradient; a block's last
+                               # conv feeds the pool, whose codes already carry the sign
+                               emit_relu_bits=fused_relu and i < num_layers - 1)
             layers.append(conv)
             if batch_norm:
                 layers.append(BatchNormNHWC(out_channels))

@@ -18,7 +18,7 @@ BF16 = torch.bfloat16
 N_CU = 256
 
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
-IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256),
+IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
 WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 256),
                6: (256, 256), 7: (128, 128)}   # 5: 8-phase port, 6/7: software-pipelined fragment reads
@@ -53,6 +53,12 @@ def pick_igemm(M, N, ksteps):
         order = [16, 3]     # 8-phase counted-vmcnt schedule: +10-18 % over the 2-stage loops
     elif N > 64:
         order = [3]         # re-swept after the chunk-major K order: 128x128 beats the pipelined 256x128
+        # 512x128 8-phase tile (one workgroup per CU): +11 % on conv2_2 forward, +3 % on its data
+        # gradient at batch 256 (bench/bench_igemm17.py), but only while the last round of tiles
+        # is nearly full (conv3_1's data gradient, 6.1 rounds: -6 %)
+        t512 = _cdiv(M, 512)
+        if igemm_512 and t512 >= 8 * N_CU and t512 >= 0.93 * _cdiv(t512, N_CU) * N_CU:
+            return 17, 1
     else:
         order = [2, 4]
     cfg = order[-1]
@@ -144,6 +150,8 @@ class _ColsumSlot(object):
 colsum_slot = _ColsumSlot()
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
+igemm_512 = _os.environ.get("DTP_IGEMM_512", "1") != "0"              # A/B switch: 512x128 8-phase tile
+relu_bitmask = _os.environ.get("DTP_RELU_BITMASK", "1") != "0"        # A/B switch: 1-bit ReLU masks for dgrad
 
 
 def colsum_parts(parts, nparts, C, out, n_valid=None, beta=0.0):
@@ -168,7 +176,8 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
-           mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None):
+           mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
+           bits_out=None):
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
@@ -186,7 +195,14 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
         nparts = _cdiv(M, IGEMM_TILES[cfg][0])
         cs_part = workspace.get("colsum_parts", nparts * Ncols, torch.float32, A.device)
         colsum_slot.put(out, cs_part, nparts, Ncols)
-    rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(out), ptr(partial), ptr(cs_part),
+    if nsplit > 1 or out_fp32:          # the 1-bit masks live in the bf16 C-image epilogue only
+        if bits_out is not None:
+            raise ValueError("igemm: bits_out needs the single-pass bf16 epilogue")
+        mask_bits = None
+    if mask_bits is not None:
+        mask_src = None
+    rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), ptr(mask_src), ptr(mask_bits), ptr(bits_out), ptr(out),
+                                 ptr(partial), ptr(cs_part),
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  ptr(seed_ptr), int(fp8), ptr(fp8_scales[0]) if fp8 else None,
@@ -195,17 +211,24 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     return out
 
 
-def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None):
+def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None, bits_out=None):
     """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip)."""
-    rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out), ptr(codes),
+    rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out), ptr(codes), ptr(bits_out),
                                  ptr(workspace.zero_page(x.device)), N, H, W, O, int(relu), float(mask_scale),
                                  stream())
     check(rc, "conv_c64")
     return out
 
 
-def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
-    """y = relu(conv3x3_same(x, w) + bias); x [N,H,W,C] bf16, w [Cout, 9*C] bf16, bias f32 [Cout]."""
+def relu_bits_for(out):
+    """Empty 1-bit-per-element mask buffer for a bf16 activation (byte i covers elements 8i..8i+7)."""
+    return torch.empty(out.numel() // 8, dtype=torch.uint8, device=out.device)
+
+
+def conv3x3_fprop(x, w, bias=None, relu=True, out=None, want_bits=False):
+    """y = relu(conv3x3_same(x, w) + bias); x [N,H,W,C] bf16, w [Cout, 9*C] bf16, bias f32 [Cout].
+    ``want_bits``: also return (y > 0) packed 1 bit per element — the ReLU-backward mask the data
+    gradient of the NEXT convolution applies to its output (16x fewer bytes than re-reading y)."""
     _need(x, BF16, "x")
     _need(w, BF16, "w")
     N, H, W, C = x.shape
@@ -222,9 +245,18 @@ def conv3x3_fprop(x, w, bias=None, relu=True, out=None):
         _need(out, BF16, "out")
         if out.numel() != N * H * W * Cout:
             raise ValueError("out size")
+    bits = None
+    if want_bits:
+        M, ks = N * H * W, 9 * (C // 64)
+        c64 = C == 64 and Cout in (64, 128) and "igemm" not in _overrides
+        if c64 or pick_igemm(M, Cout, ks)[1] == 1:       # split-K passes have no bf16 epilogue to pack from
+            bits = relu_bits_for(out)
     if C == 64 and Cout in (64, 128) and "igemm" not in _overrides:
-        return _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0)
-    return _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0)
+        _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0, bits_out=bits)
+    else:
+        _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0,
+               bits_out=bits)
+    return (out, bits) if want_bits else out
 
 
 def conv_pool_fusable(C, Cout, H, W):
@@ -250,8 +282,10 @@ def conv3x3_relu_pool_fprop(x, w, bias):
     return y, codes
 
 
-def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
-    """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout]."""
+def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None):
+    """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout].
+    ``mask_bits`` (from ``conv3x3_fprop(..., want_bits=True)`` of the layer that produced
+    ``mask_src``) replaces the 2-byte-per-element mask read by 1 bit per element."""
     _need(dy, BF16, "dy")
     _need(wd, BF16, "wd")
     N, H, W, Co = dy.shape
@@ -262,13 +296,17 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None):
         _need(mask_src, BF16, "mask_src")
         if mask_src.numel() != N * H * W * Cin:
             raise ValueError("mask_src size")
+    if mask_bits is not None:
+        if mask_src is None or mask_bits.dtype != torch.uint8 or not mask_bits.is_cuda \
+                or mask_bits.numel() * 8 != N * H * W * Cin or not mask_bits.is_contiguous():
+            raise ValueError("mask_bits: uint8 CUDA tensor of numel(dx)/8 bytes next to its mask_src")
     if out is None:
         out = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
     if Co == 64 and Cin in (64, 128) and "igemm" not in _overrides:
         return _conv_c64(dy, wd, None, mask_src, out, N, H, W, Cin, False, mask_scale)
     # a masked data-gradient is the dY of the convolution below: leave its column sums behind
     return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
-                  mask_scale, 0.0, 0, want_colsum=mask_src is not None)
+                  mask_scale, 0.0, 0, want_colsum=mask_src is not None, mask_bits=mask_bits)
 
 
 def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None, seed_ptr=None):

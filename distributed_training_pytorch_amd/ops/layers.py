@@ -117,9 +117,16 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, layer):
         arena = _arena_of(layer)
-        y = K.conv3x3_fprop(x, arena.lp(weight), bias.detach() if bias is not None else None, relu=layer.relu)
+        # 1-bit ReLU masks: this layer packs (y > 0) for the data gradient of the NEXT convolution and
+        # picks up the bits its producer left on x (tensor attribute set in Conv3x3.forward)
+        want_bits = K.relu_bitmask and layer.relu and layer.emit_relu_bits
+        y = K.conv3x3_fprop(x, arena.lp(weight), bias.detach() if bias is not None else None, relu=layer.relu,
+                            want_bits=want_bits)
+        if want_bits:
+            y, layer._bits_tmp = y
         ctx.layer = layer
         ctx.has_bias = bias is not None
+        ctx.mask_bits = getattr(x, "_dtp_relu_bits", None) if (K.relu_bitmask and layer.input_is_relu_out) else None
         ctx.save_for_backward(x, y, weight, bias)
         return y
 
@@ -149,7 +156,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             Ci = weight.shape[1]
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
-            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)    # join before the reducer ships the gradient
         if ctx.has_bias:
@@ -168,6 +175,7 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         arena = _arena_of(layer)
         y, codes = K.conv3x3_relu_pool_fprop(x, arena.lp(weight), bias.detach())
         ctx.layer = layer
+        ctx.mask_bits = getattr(x, "_dtp_relu_bits", None) if (K.relu_bitmask and layer.input_is_relu_out) else None
         ctx.save_for_backward(x, codes, weight, bias)
         return y
 
@@ -191,7 +199,7 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
-            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None)
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
@@ -223,12 +231,14 @@ class Conv3x3(_Conv3x3Derived, FusedLayer):
     """3x3, stride 1, pad 1 convolution (+bias, +ReLU fused).  ``weight`` keeps torch's logical
     ``[Cout, Cin, 3, 3]`` shape (checkpoint compatibility with reference model/vgg16.py:9,12)."""
 
-    def __init__(self, in_channels, out_channels, relu=True, input_is_relu_out=False, grad_premasked=False):
+    def __init__(self, in_channels, out_channels, relu=True, input_is_relu_out=False, grad_premasked=False,
+                 emit_relu_bits=True):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.relu = relu
         self.input_is_relu_out = input_is_relu_out
         self.grad_premasked = grad_premasked
+        self.emit_relu_bits = emit_relu_bits       # False: the consumer is not a masking Conv3x3 (e.g. a pool)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3))
         self.bias = nn.Parameter(torch.zeros(out_channels))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
@@ -237,7 +247,11 @@ class Conv3x3(_Conv3x3Derived, FusedLayer):
         if not x.is_cuda:
             y = F.conv2d(x, self.weight, self.bias, padding=1)
             return F.relu(y) if self.relu else y
-        return _Conv3x3Fn.apply(x, self.weight, self.bias, self)
+        y = _Conv3x3Fn.apply(x, self.weight, self.bias, self)
+        bits = self.__dict__.pop("_bits_tmp", None)
+        if bits is not None:
+            y._dtp_relu_bits = bits          # travels with the activation to the next Conv3x3
+        return y
 
     def extra_repr(self):
         return "%d, %d, relu=%s" % (self.in_channels, self.out_channels, self.relu)

@@ -65,7 +65,7 @@ def test_conv3x3_fprop(shape):
     _close(y2, _ref_conv(x, w, None, False), 2e-2, 2e-2, "fprop-nobias%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 16])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 16, 17])
 def test_conv3x3_fprop_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(1)
@@ -396,10 +396,13 @@ def test_conv1_fprop_wgrad(shape, in_dtype):
     assert not torch.equal(g1, gw.float()) or (y.float() > 0).all()
 
 
-@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (3, 9, 11, 64, 256), (2, 56, 56, 256, 256)])
-def test_conv3x3_8phase_schedule(shape):
-    """cfg 16: 8-phase loop with LDS-DMA in flight across barriers — even and odd K-tile counts,
-    M/N tails, split-K, dgrad mask epilogue; repeated to screen for DMA/read races."""
+@pytest.mark.parametrize("cfg", [16, 17])
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (3, 9, 11, 64, 256), (2, 56, 56, 256, 256),
+                                   (3, 30, 26, 128, 128)])
+def test_conv3x3_8phase_schedule(shape, cfg):
+    """cfg 16 (256x256, 2x4 waves) / 17 (512x128, 4x2 waves): 8-phase loop with LDS-DMA in flight
+    across barriers — even and odd K-tile counts, M/N tails, split-K; repeated to screen for
+    DMA/read races."""
     k = _k()
     N, H, W, C, Co = shape
     torch.manual_seed(21)
@@ -408,7 +411,7 @@ def test_conv3x3_8phase_schedule(shape):
     b = torch.randn(Co, device="cuda")
     ref = _ref_conv(x, w, b, True)
     for nsplit in (1, 2, 3):
-        k._overrides["igemm"] = lambda M, Nc, ks: (16, nsplit)
+        k._overrides["igemm"] = lambda M, Nc, ks: (cfg, nsplit)
         try:
             outs = [k.conv3x3_fprop(x, w, b, relu=True) for _ in range(4)]
         finally:
@@ -418,7 +421,7 @@ def test_conv3x3_8phase_schedule(shape):
             assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16, 17])
 def test_fused_bias_grad_from_dgrad_epilogue(cfg):
     """The masked data-gradient kernel leaves per-tile column sums of its output behind; the
     consumer's bias gradient built from them equals the column sum of the stored bf16 tensor."""
@@ -555,3 +558,47 @@ def test_fused_conv_relu_pool_matches_separate_kernels(shape):
     dx_ref = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes_ref, in_shape=tuple(y_full.shape))
     dx = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes, in_shape=tuple(y_full.shape))
     assert torch.equal(dx, dx_ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 12, 128, 256), (3, 9, 11, 64, 128), (2, 14, 14, 256, 192), (1, 30, 34, 64, 64)])
+def test_relu_bitmask_roundtrip(shape):
+    """conv3x3_fprop(want_bits) packs (y > 0) one bit per element (igemm and conv_c64 epilogues); the
+    data gradient masked from those bits is bit-identical to the one masked from y itself."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(31)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    if C != 64:                       # tiny test grids would take split-K (no bf16 epilogue, no bits)
+        k._overrides["igemm"] = lambda M, Nc, ks: (3, 1)
+    try:
+        y, bits = k.conv3x3_fprop(x, w, b, relu=True, want_bits=True)
+        y_plain = k.conv3x3_fprop(x, w, b, relu=True)
+    finally:
+        k._overrides.pop("igemm", None)
+    assert bits is not None and bits.numel() * 8 == y.numel()
+    assert torch.equal(y, y_plain)
+    pos = (y.float() > 0).view(-1, 8).to(torch.int32)
+    ref_bits = (pos * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8)
+    assert torch.equal(bits, ref_bits)
+    # consumer: a conv with Co inputs -> its dgrad output has Co channels and is masked by y
+    C2 = 128
+    dy = _rand(N, H, W, C2)
+    wd = _rand(Co, 9 * C2, scale=(2.0 / (9 * C2)) ** 0.5)
+    for cfg in (None, 3, 16, 17):
+        if cfg is not None:
+            k._overrides["igemm"] = lambda M, Nc, ks, cfg=cfg: (cfg, 1)
+        try:
+            a = k.conv3x3_dgrad(dy, wd, mask_src=y, mask_scale=1.0)
+            cs_a = torch.empty(Co, device="cuda")
+            k.bias_grad(a.view(-1, Co), cs_a)
+            bm = k.conv3x3_dgrad(dy, wd, mask_src=y, mask_scale=1.0, mask_bits=bits)
+            cs_b = torch.empty(Co, device="cuda")
+            k.bias_grad(bm.view(-1, Co), cs_b)
+        finally:
+            k._overrides.pop("igemm", None)
+        assert torch.equal(a, bm), "cfg %s" % cfg
+        assert torch.equal(cs_a, cs_b)
+    with pytest.raises(ValueError):
+        k.conv3x3_dgrad(dy, wd, mask_src=y, mask_bits=bits[:-1])

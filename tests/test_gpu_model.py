@@ -269,6 +269,57 @@ def test_fused_bias_grads_match_standalone_colsum():
             assert (fused[s] - plain[s]).abs().max().item() <= 1e-4 * ref + 1e-7, n
 
 
+def test_relu_bitmask_model_gradients_bit_identical():
+    """Whole model: data gradients masked from the 1-bit (y > 0) masks the forward kernels pack are
+    bit-identical to the ones masked by re-reading the activation (DTP_RELU_BITMASK A/B switch),
+    and the masked convolutions really received the bits."""
+    from distributed_training_pytorch_amd.ops import kernels as K
+    from distributed_training_pytorch_amd.ops.layers import Conv3x3, SoftmaxCrossEntropy
+    _, gpu = _models(seed=9)
+    gpu.eval()                                   # dropout off: both runs see the same masks
+    a = gpu.param_arena
+    crit = SoftmaxCrossEntropy()
+    torch.manual_seed(10)
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 3, (8,), device="cuda")
+    seen = []
+    orig = K.conv3x3_dgrad
+
+    def spy(*args, **kw):
+        seen.append(kw.get("mask_bits") is not None)
+        return orig(*args, **kw)
+
+    def run():
+        a.zero_grad()
+        crit(gpu(x), y).backward()
+        torch.cuda.synchronize()
+        return a.flat_grad.clone()
+
+    K.conv3x3_dgrad = spy
+    n_masked = sum(1 for m in gpu.modules() if isinstance(m, Conv3x3) and m.input_is_relu_out)
+    assert n_masked >= 7
+    try:
+        # (a) the shipped tile picker (small grids: split-K producers emit no bits, conv_c64 does);
+        # (b) single-pass 128x128 tiles everywhere: every masked convolution must receive bits
+        for override, expect in ((None, 1), ((3, 1), n_masked)):
+            if override is not None:
+                K._overrides["igemm"] = lambda M, Nc, ks, o=override: o
+            assert K.relu_bitmask
+            del seen[:]
+            with_bits = run()
+            assert sum(seen) >= expect, (override, seen)
+            K.relu_bitmask = False
+            del seen[:]
+            plain = run()
+            K.relu_bitmask = True
+            assert not any(seen)
+            assert torch.equal(with_bits, plain), override
+    finally:
+        K.relu_bitmask = True
+        K.conv3x3_dgrad = orig
+        K._overrides.pop("igemm", None)
+
+
 def test_hip_graph_step_matches_eager_and_redraws_dropout():
     """GraphedTrainStep: (a) with dropout off, N graph replays == N eager steps bit for bit;
     (b) with dropout on, replays draw different masks (device-resident seed) and still train;
