@@ -31,7 +31,7 @@ _SIGS = {
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],
     "dtp_conv_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_void_p],
+                     c_float, c_int, c_void_p, c_void_p],
     "dtp_wgrad_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
     "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],

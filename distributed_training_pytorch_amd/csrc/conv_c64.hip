@@ -21,7 +21,10 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 struct ConvC64Params {
-  const char* X;         // [N*H*W][64] bf16
+  const char* X;         // [N*H*W][ldx] bf16: the 64 reduction channels are a 128-byte slice of each pixel row
+  const char* acc_src;   // optional [N*H*W][O] bf16 added to the accumulator (may alias out): lets a
+                         // 128-channel reduction run as two 64-channel passes, the second in place
+  int ldx;               // pixel stride of X in elements (64, or 128 for a half of a 128-channel tensor)
   const char* Wt;        // [O][9*64] bf16
   const float* bias;     // [O] or null
   const char* mask_src;  // [N*H*W][O] bf16 or null
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
         const int w = w0 - 1 + pos;
         const bool ok = row_ok && pos < 34 && w >= 0 && w < p.W;
         const int lc = xpc ^ ((pos >> 1) & 7);
-        const char* g = ok ? p.X + ((img_px + (size_t)hrow * p.W + w) * 64 + lc * 8) * 2 : p.zero_page;
+        const char* g = ok ? p.X + ((img_px + (size_t)hrow * p.W + w) * p.ldx + lc * 8) * 2 : p.zero_page;
         glds16(g, slot + wi * 1024);
       }
     }
@@ -110,6 +113,14 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   for (int h = h0; h < h1; ++h) {
     __syncthreads();                     // row h+1 landed (vmcnt(0)+barrier); step h-1 done everywhere
     if (h + 1 < h1) stage_x(h + 2);
+    // earlier partial sums (two-pass 128-channel reduction): issued now, added after the MFMAs.
+    // Register r holds cout 8*(r>>2) + 4*hb + (r&3) of pixel l31 -> four 8-byte loads per lane.
+    u32x2_t pv[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+    if (!POOL && p.acc_src && px_ok) {
+      const char* ap = p.acc_src + ((img_px + (size_t)h * p.W + w0 + l31) * O + wave * 32 + 4 * hb) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[q] = *(const u32x2_t*)(ap + q * 16);
+    }
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
@@ -124,6 +135,15 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
           const bf16x8_t xf = *(const bf16x8_t*)(slot + xbase[dxi] + (c << 4));
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][k], xf, acc, 0, 0, 0);
         }
+      }
+    }
+    if (!POOL && p.acc_src) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[q * 4 + 0] += __uint_as_float(pv[q][0] << 16);
+        acc[q * 4 + 1] += __uint_as_float(pv[q][0] & 0xFFFF0000u);
+        acc[q * 4 + 2] += __uint_as_float(pv[q][1] << 16);
+        acc[q * 4 + 3] += __uint_as_float(pv[q][1] & 0xFFFF0000u);
       }
     }
     if constexpr (POOL) {
@@ -275,11 +295,14 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 // codes != null: fused ReLU + 2x2 max-pool epilogue; out is then [N,H/2,W/2,O] and codes [N,H/2,W/2,O/8] uint32
 extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, const void* mask_src, void* out,
                             void* codes, void* bits_out, const void* zero_page, int N, int H, int W, int O, int relu,
-                            float mask_scale, hipStream_t stream) {
+                            float mask_scale, int ldx, const void* acc_src, hipStream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || (O != 64 && O != 128)) return -10;
+  if (ldx < 64 || (ldx & 7)) return -14;
+  if (acc_src && codes) return -15;
   ConvC64Params p;
   p.X = (const char*)X; p.Wt = (const char*)Wt; p.bias = bias; p.mask_src = (const char*)mask_src;
   p.out = (char*)out; p.zero_page = (const char*)zero_page;
+  p.ldx = ldx; p.acc_src = (const char*)acc_src;
   p.N = N; p.H = H; p.W = W; p.relu = relu; p.mask_scale = mask_scale;
   p.S = (W + 31) / 32;
   const long units = (long)N * p.S;

@@ -150,6 +150,9 @@ class _ColsumSlot(object):
 colsum_slot = _ColsumSlot()
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
+# conv2_1 dgrad as 2 conv_c64 passes: measured 640 vs 662 TF/s for the implicit GEMM at batch 256 and
+# no end-to-end difference (bench/bench_dgrad_c128.py, profiles/18_*): opt-in only
+two_pass_c128 = _os.environ.get("DTP_DGRAD_TWO_PASS", "0") == "1"
 igemm_512 = _os.environ.get("DTP_IGEMM_512", "1") != "0"              # A/B switch: 512x128 8-phase tile
 relu_bitmask = _os.environ.get("DTP_RELU_BITMASK", "1") != "0"        # A/B switch: 1-bit ReLU masks for dgrad
 
@@ -211,11 +214,14 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     return out
 
 
-def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None, bits_out=None):
-    """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip)."""
+def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None, bits_out=None, ldx=64,
+              acc_src=None):
+    """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip).
+    ``ldx``: pixel stride of x in elements (x may be a 64-channel slice of a wider tensor);
+    ``acc_src``: bf16 partial sums added before the epilogue (may be ``out`` itself)."""
     rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out), ptr(codes), ptr(bits_out),
                                  ptr(workspace.zero_page(x.device)), N, H, W, O, int(relu), float(mask_scale),
-                                 stream())
+                                 int(ldx), ptr(acc_src), stream())
     check(rc, "conv_c64")
     return out
 
@@ -282,7 +288,14 @@ def conv3x3_relu_pool_fprop(x, w, bias):
     return y, codes
 
 
-def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None):
+def split_dgrad_weight(wd, Cin, Co):
+    """The dgrad-layout weight [Cin][9][Co] cut into its two 64-channel reduction halves, each
+    [Cin][9*64] (operands of the two-pass conv_c64 data gradient)."""
+    w3 = wd.view(Cin, 9, Co)
+    return (w3[:, :, :64].contiguous().view(Cin, 9 * 64), w3[:, :, 64:128].contiguous().view(Cin, 9 * 64))
+
+
+def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None, wd_halves=None):
     """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout].
     ``mask_bits`` (from ``conv3x3_fprop(..., want_bits=True)`` of the layer that produced
     ``mask_src``) replaces the 2-byte-per-element mask read by 1 bit per element."""
@@ -304,6 +317,15 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=Non
         out = torch.empty((N, H, W, Cin), dtype=BF16, device=dy.device)
     if Co == 64 and Cin in (64, 128) and "igemm" not in _overrides:
         return _conv_c64(dy, wd, None, mask_src, out, N, H, W, Cin, False, mask_scale)
+    if Co == 128 and Cin == 64 and two_pass_c128 and "igemm" not in _overrides:
+        # conv2_1's data gradient: a 64-wide output makes the generic kernel LDS-fill bound
+        # (395 TF/s); two register-resident-filter passes over the two halves of the 128 reduction
+        # channels, the second accumulating in place, run at the conv_c64 rate instead.  The
+        # first pass's partial sums are rounded to bf16 once (one extra rounding of a bf16 result).
+        lo, hi = wd_halves if wd_halves is not None else split_dgrad_weight(wd, Cin, Co)
+        dy2 = dy.view(-1, Co)
+        _conv_c64(dy2, lo, None, None, out, N, H, W, Cin, False, 1.0, ldx=Co)
+        return _conv_c64(dy2[:, 64:], hi, None, mask_src, out, N, H, W, Cin, False, mask_scale, ldx=Co, acc_src=out)
     # a masked data-gradient is the dY of the convolution below: leave its column sums behind
     return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
                   mask_scale, 0.0, 0, want_colsum=mask_src is not None, mask_bits=mask_bits)

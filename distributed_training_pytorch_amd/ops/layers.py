@@ -156,7 +156,8 @@ class _Conv3x3Fn(torch.autograd.Function):
             Ci = weight.shape[1]
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
-            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits)
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
+                                 wd_halves=layer._wd_halves(wd))
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)    # join before the reducer ships the gradient
         if ctx.has_bias:
@@ -199,7 +200,8 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
-            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits)
+            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
+                                 wd_halves=layer._wd_halves(wd))
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
@@ -224,7 +226,17 @@ class _Conv3x3Derived(object):
             return []
         arena = _arena_of(self)
         Co, Ci = self.out_channels, self.in_channels
-        return [("wd", lambda: K.conv_weight_to_dgrad(arena.lp(self.weight), Co, Ci))]
+        out = [("wd", lambda: K.conv_weight_to_dgrad(arena.lp(self.weight), Co, Ci))]
+        if Co == 128 and Ci == 64 and K.two_pass_c128:
+            out.append(("wd_halves", lambda: K.split_dgrad_weight(self._cached("wd", out[0][1]), Ci, Co)))
+        return out
+
+    def _wd_halves(self, wd):
+        """Reduction halves of the dgrad weight for the two-pass 128 -> 64 data gradient (else None)."""
+        Co, Ci = self.out_channels, self.in_channels
+        if not (Co == 128 and Ci == 64 and K.two_pass_c128):
+            return None
+        return self._cached("wd_halves", lambda: K.split_dgrad_weight(wd, Ci, Co))
 
 
 class Conv3x3(_Conv3x3Derived, FusedLayer):

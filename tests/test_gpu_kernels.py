@@ -602,3 +602,32 @@ def test_relu_bitmask_roundtrip(shape):
         assert torch.equal(cs_a, cs_b)
     with pytest.raises(ValueError):
         k.conv3x3_dgrad(dy, wd, mask_src=y, mask_bits=bits[:-1])
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 34, 64, 128), (1, 112, 112, 64, 128), (3, 17, 9, 64, 128)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv3x3_dgrad_two_pass_c128(shape, masked):
+    """128 reduction channels -> 64 outputs (conv2_1's data gradient): two conv_c64 passes over the
+    channel halves, the second accumulating in place, against the f32 reference and against the
+    generic implicit GEMM (one extra bf16 rounding of the first half's partial sums)."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(41)
+    dy = _rand(N, H, W, Co)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * Co)) ** 0.5)
+    xmask = _rand(N, H, W, C) if masked else None
+    wd = k.conv_weight_to_dgrad(w, Co, C)
+    k.two_pass_c128 = True            # opt-in path (DTP_DGRAD_TWO_PASS=1)
+    try:
+        dx = k.conv3x3_dgrad(dy, wd, mask_src=xmask)
+        dx2 = k.conv3x3_dgrad(dy, wd, mask_src=xmask, wd_halves=k.split_dgrad_weight(wd, C, Co))
+    finally:
+        k.two_pass_c128 = False
+    assert torch.equal(dx, dx2)
+    w4 = w.float().view(Co, 3, 3, C).permute(0, 3, 1, 2).contiguous()
+    ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1)
+    if masked:
+        ref = ref * (xmask.float() > 0)
+    _close(dx, ref, 2e-2, 2e-2, "two-pass dgrad%s" % (shape,))
+    one = k.conv3x3_dgrad(dy, wd, mask_src=xmask)
+    _close(dx, one.float(), 2e-2, 1e-2, "two-pass vs igemm%s" % (shape,))
