@@ -111,7 +111,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   stage_x(h0);
   stage_x(h0 + 1);
   for (int h = h0; h < h1; ++h) {
-    __syncthreads();                     // row h+1 landed (vmcnt(0)+barrier); step h-1 done everywhere
+    sync_lds_dma();                      // row h+1 landed (explicit vmcnt(0) + barrier); step h-1 done everywhere
     if (h + 1 < h1) stage_x(h + 2);
     // earlier partial sums (two-pass 128-channel reduction): issued now, added after the MFMAs.
     // Register r holds cout 8*(r>>2) + 4*hb + (r&3) of pixel l31 -> four 8-byte loads per lane.

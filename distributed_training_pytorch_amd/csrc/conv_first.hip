@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
         }
       }
     }
-    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) is emitted before the barrier)
+    sync_lds_dma();    // dY tile (LDS-DMA) and the im2col image landed everywhere
     if (self_mask) {
       // y = W * im2col + b for this wave's 64 pixels; zero dY (in its LDS image) where y <= 0.
       // The wave masks exactly the rows it reads below, so a wave-level fence is enough.

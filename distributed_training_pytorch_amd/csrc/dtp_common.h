@@ -32,6 +32,16 @@ DTP_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Barrier that PUBLISHES LDS-DMA data to the other waves of the workgroup.  A global_load_lds is
+// retired only on the issuing wave's vmcnt; hipcc's __syncthreads() emitted the s_waitcnt vmcnt(0)
+// in front of its s_barrier in some instantiations and not in others (conv_c64<64, POOL> had none
+// inside its row loop: one stale input row per ~10^3 workgroups whenever HBM was busy with another
+// stream's kernels).  Every barrier that hands DMA'd LDS to other waves goes through here.
+DTP_DEVINL void sync_lds_dma() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
 // XCD a contiguous run of tile ids for L2 reuse (cdna_hip_programming.md T1). Speed only.
 DTP_DEVINL int xcd_remap(int bid, int nwg) {

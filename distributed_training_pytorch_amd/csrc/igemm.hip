@@ -434,19 +434,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     // handled above
   } else if (PIPE == 0) {
     for (int kt = kbeg; kt < kend; ++kt) {
-      __syncthreads();   // stage kt landed everywhere; everyone is done reading the other buffer
+      sync_lds_dma();    // stage kt landed everywhere; everyone is done reading the other buffer
       if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
       compute(buf);
       buf ^= 1;
     }
   } else {
     for (int kt = kbeg; kt < kend - 1; ++kt) {
-      __syncthreads();
+      sync_lds_dma();
       step(kt, buf, std::true_type{});
       buf ^= 1;
     }
     if (kbeg < kend) {
-      __syncthreads();
+      sync_lds_dma();
       step(kend - 1, buf, std::false_type{});
     }
   }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
   if (kbeg < kend) stage(kbeg, 0);
   int buf = 0;
   for (int kt = kbeg; kt < kend; ++kt) {
-    __syncthreads();
+    sync_lds_dma();      // stage kt landed everywhere; everyone is done reading the other buffer
     if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
     if (SWP) compute_swp(buf);
     else compute(buf);

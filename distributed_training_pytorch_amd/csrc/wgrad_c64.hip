@@ -125,7 +125,7 @@ __global__ __launch_bounds__(COUT * 4) void wgrad_c64_kernel(const WgC64Params p
     stage_x(h0 + 1);
     stage_dy(h0);
     for (int h = h0; h < h1; ++h) {
-      __syncthreads();                   // loads for step h landed (vmcnt(0) + barrier); step h-1 consumed
+      sync_lds_dma();                    // loads for step h landed (explicit vmcnt(0) + barrier); step h-1 consumed
       if (h + 1 < h1) {
         stage_x(h + 2);
         stage_dy(h + 1);

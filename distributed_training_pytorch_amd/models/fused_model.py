@@ -23,6 +23,8 @@ contiguous ``state_dict`` entries) lives here and is reusable:
 ``attach_arena(module)`` does the same for an already-constructed plain ``nn.Module`` (one shot:
 call it again after moving the module to another device).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -104,7 +106,7 @@ class FusedModel(nn.Module):
             return
         self._derived_epoch = arena.lp_epoch
         from ..ops import layers as L
-        if not L.OVERLAP_WGRAD:
+        if not L.OVERLAP_WGRAD or os.environ.get("DTP_PREFETCH_DERIVED", "1") == "0":
             return
         side = L._side_stream(device)
         side.wait_stream(torch.cuda.current_stream())

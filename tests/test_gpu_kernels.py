@@ -631,3 +631,42 @@ def test_conv3x3_dgrad_two_pass_c128(shape, masked):
     _close(dx, ref, 2e-2, 2e-2, "two-pass dgrad%s" % (shape,))
     one = k.conv3x3_dgrad(dy, wd, mask_src=xmask)
     _close(dx, one.float(), 2e-2, 1e-2, "two-pass vs igemm%s" % (shape,))
+
+
+def test_lds_dma_kernels_are_bitwise_repeatable_under_memory_contention():
+    """Regression: conv_c64<64, POOL> had no s_waitcnt vmcnt(0) in front of its row-loop barrier
+    (hipcc's __syncthreads() emits it in some instantiations only), so an input row staged by
+    LDS-DMA could be read before it landed whenever HBM was busy with another stream's kernels —
+    one wrong pooled row in ~5 % of tiny training runs.  All DMA-publishing barriers now go through
+    sync_lds_dma(); here the DMA kernels run next to a bandwidth hog on a second stream and every
+    repetition must match the first bit for bit."""
+    k = _k()
+    torch.manual_seed(51)
+    x = _rand(4, 32, 32, 64)
+    w64 = _rand(64, 576, scale=0.06)
+    w128 = _rand(128, 576, scale=0.06)
+    b64, b128 = torch.randn(64, device="cuda"), torch.randn(128, device="cuda")
+    x2 = _rand(4, 16, 16, 128)
+    w2 = _rand(256, 9 * 128, scale=0.04)
+    dy = _rand(4, 32, 32, 64)
+    gw = torch.empty(64, 576, device="cuda")
+    hog_src = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    cases = [
+        ("conv+pool 64", lambda: k.conv3x3_relu_pool_fprop(x, w64, b64)[0]),
+        ("conv+pool 128", lambda: k.conv3x3_relu_pool_fprop(x, w128, b128)[0]),
+        ("conv_c64", lambda: k.conv3x3_fprop(x, w64, b64, True)),
+        ("igemm", lambda: k.conv3x3_fprop(x2, w2, None, True)),
+        ("wgrad_c64", lambda: k.conv3x3_wgrad(dy, x, gw).clone()),
+    ]
+    for name, fn in cases:
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        for i in range(150):
+            if i % 3 == 0:
+                with torch.cuda.stream(side):
+                    hog_dst.copy_(hog_src)
+            out = fn()
+            assert torch.equal(out, ref), "%s: repetition %d differs" % (name, i)
+        torch.cuda.synchronize()
