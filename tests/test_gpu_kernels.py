@@ -633,6 +633,14 @@ def test_conv3x3_dgrad_two_pass_c128(shape, masked):
     _close(dx, one.float(), 2e-2, 1e-2, "two-pass vs igemm%s" % (shape,))
 
 
+def _with_cfg(k, cfg, fn):
+    k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)
+    try:
+        return fn()
+    finally:
+        k._overrides.pop("igemm", None)
+
+
 def test_lds_dma_kernels_are_bitwise_repeatable_under_memory_contention():
     """Regression: conv_c64<64, POOL> had no s_waitcnt vmcnt(0) in front of its row-loop barrier
     (hipcc's __syncthreads() emits it in some instantiations only), so an input row staged by
@@ -650,6 +658,8 @@ def test_lds_dma_kernels_are_bitwise_repeatable_under_memory_contention():
     w2 = _rand(256, 9 * 128, scale=0.04)
     dy = _rand(4, 32, 32, 64)
     gw = torch.empty(64, 576, device="cuda")
+    _dy2 = _rand(4, 16, 16, 256)
+    _gw2 = torch.empty(256, 9 * 128, device="cuda")
     hog_src = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device="cuda").normal_()
     hog_dst = torch.empty_like(hog_src)
     side = torch.cuda.Stream()
@@ -658,6 +668,9 @@ def test_lds_dma_kernels_are_bitwise_repeatable_under_memory_contention():
         ("conv+pool 128", lambda: k.conv3x3_relu_pool_fprop(x, w128, b128)[0]),
         ("conv_c64", lambda: k.conv3x3_fprop(x, w64, b64, True)),
         ("igemm", lambda: k.conv3x3_fprop(x2, w2, None, True)),
+        ("igemm 8-phase 256x256", lambda: _with_cfg(k, 16, lambda: k.conv3x3_fprop(x2, w2, None, True))),
+        ("igemm 8-phase 512x128", lambda: _with_cfg(k, 17, lambda: k.conv3x3_fprop(x2, w2, None, True))),
+        ("wgrad_tt", lambda: k.conv3x3_wgrad(_dy2, x2, _gw2).clone()),
         ("wgrad_c64", lambda: k.conv3x3_wgrad(dy, x, gw).clone()),
     ]
     for name, fn in cases:
