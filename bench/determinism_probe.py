@@ -20,6 +20,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--size", type=int, default=32)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--bn", action="store_true")
+    ap.add_argument("--fp8", action="store_true")
+    ap.add_argument("--adamw", action="store_true")
+    ap.add_argument("--grad-bf16", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.0)
     args = ap.parse_args()
     torch.manual_seed(21)
     xs = [torch.randn(args.batch, 3, args.size, args.size, device="cuda") for _ in range(args.steps)]
@@ -28,8 +33,13 @@ def main():
     bad = 0
     for t in range(args.trials):
         torch.manual_seed(22)
-        m = VGG16(3, 3, True, dropout=0.0).to("cuda").train()
-        o = FusedSGD(m, lr=0.002, momentum=0.9, weight_decay=1e-4)
+        m = VGG16(3, 3, True, dropout=args.dropout, batch_norm=args.bn, fp8_classifier=args.fp8,
+                  grad_dtype=torch.bfloat16 if args.grad_bf16 else torch.float32).to("cuda").train()
+        if args.adamw:
+            from distributed_training_pytorch_amd.ops.optim import FusedAdamW
+            o = FusedAdamW(m, lr=1e-4, weight_decay=1e-2)
+        else:
+            o = FusedSGD(m, lr=0.002, momentum=0.9, weight_decay=1e-4)
         c = SoftmaxCrossEntropy()
         a = m.param_arena
         g = None
