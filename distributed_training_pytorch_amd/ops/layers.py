@@ -29,6 +29,8 @@ _seed_counter = itertools.count(1)
 
 # run each conv layer's weight gradient on a side stream, concurrently with its data gradient
 OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
+# unmasked linear data gradient without the per-step W^T copy (A/B switch)
+LINEAR_DGRAD_TT = os.environ.get("DTP_LINEAR_DGRAD_TT", "1") == "1"
 _side_streams = {}
 # Deferred join (join the side stream only at the end of backward) is OFF by default: it needs
 # record_stream() on every activation the weight-gradient kernels read, which parks those blocks in
@@ -468,7 +470,14 @@ class _LinearFn(torch.autograd.Function):
             K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
         K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and layer._dgrad_without_wt(dy.shape[0]):
+            # dX = dY @ W as a "TT" GEMM (reduction axis slow in BOTH operands, csrc/wgrad.hip) over the
+            # weight in its native [N_out, K_in] layout: only the small dY is transposed, the 205 MB
+            # W^T copy of linear1 is neither built (0.17 ms of HBM traffic per step) nor kept
+            dyT = K.linear_weight_transpose(dy, pad_to=8)
+            dx = torch.empty((dy.shape[0], Kin), dtype=BF16, device=dy.device)
+            K.linear_wgrad(dyT, arena.lp(weight), dx, n_valid=dy.shape[0])
+        elif ctx.needs_input_grad[0]:
             arena.wait_derived()
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
@@ -481,10 +490,19 @@ class _LinearFn(torch.autograd.Function):
 
 class _LinearDerived(object):
     def derived_builders(self, needs_input_grad=True):
-        if not needs_input_grad:
+        if not needs_input_grad or self._dgrad_without_wt(None):
             return []
         arena = _arena_of(self)
         return [("wt", lambda: K.linear_weight_transpose(arena.lp(self.weight)))]
+
+    def _dgrad_without_wt(self, batch):
+        """Unmasked data gradients of wide layers (linear1) run on the transposing-read GEMM over
+        the native weight layout; ``batch=None`` asks whether the layer ever needs its W^T."""
+        ok = (LINEAR_DGRAD_TT and not self.input_is_relu_out and self.out_features % 64 == 0
+              and self.in_features % 8 == 0 and self.in_features * self.out_features >= (1 << 24))
+        if batch is None:
+            return ok
+        return ok and batch % 8 == 0
 
 
 class Linear(_LinearDerived, FusedLayer):

@@ -683,3 +683,22 @@ def test_lds_dma_kernels_are_bitwise_repeatable_under_memory_contention():
             out = fn()
             assert torch.equal(out, ref), "%s: repetition %d differs" % (name, i)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shape", [(8, 4096, 25088), (256, 4096, 4096), (24, 512, 1024)])
+def test_linear_dgrad_on_native_weight_layout(shape):
+    """dX = dY @ W computed by the transposing-read GEMM (wgrad_tt) over W [N_out, K_in] as stored —
+    the path Linear takes for unmasked wide layers instead of building W^T every step."""
+    k = _k()
+    M, Nout, Kin = shape
+    torch.manual_seed(61)
+    dy = _rand(M, Nout, scale=0.1)
+    w = _rand(Nout, Kin, scale=Nout ** -0.5)
+    dyT = k.linear_weight_transpose(dy, pad_to=8)
+    assert tuple(dyT.shape) == (Nout, M) and torch.equal(dyT, dy.t().contiguous())
+    dx = torch.empty(M, Kin, dtype=BF16, device="cuda")
+    k.linear_wgrad(dyT, w, dx, n_valid=M)
+    ref = dy.float() @ w.float()
+    _close(dx, ref, 2e-2, 2e-2, "tt dgrad %s" % (shape,))
+    via_wt = k.linear_dgrad(dy, k.linear_weight_transpose(w))
+    _close(dx, via_wt.float(), 2e-2, 1e-2, "tt vs nt dgrad %s" % (shape,))
