@@ -22,8 +22,13 @@ DTP_DEVINL bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// Two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, same bits as two
+// scalar conversions; the scalar form compiled to two converts plus a v_perm per pair).
 DTP_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  typedef float f32v2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16v2_t __attribute__((ext_vector_type(2)));
+  const f32v2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
 // Async global->LDS copy of 16 bytes per lane. LDS destination is wave-uniform base + lane*16.

@@ -52,6 +52,8 @@ struct IgemmParams {
   int ksteps_per_split;
   int tiles_m, tiles_n;
   int k_order;            // 3x3 reduction order: 0 = tap-major (tap, channel chunk), 1 = chunk-major (chunk, tap)
+  int stagger;            // PIPE == 2: first-round workgroup on CU slot j of its XCD starts j * stagger * 512 cycles late
+  unsigned long long* stamps;   // DEBUG (DTP_IGEMM_STAMPS): per workgroup {hw_id|xcc, t_entry, t_loop, t_loop_end, t_exit}
 };
 
 // 16x16x32 MFMA step on one 16-byte fragment pair.  FP8: the 16 bytes are 16 OCP e4m3 values, fed
@@ -98,6 +100,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   const int kbeg = blockIdx.y * p.ksteps_per_split;
   int kend = kbeg + p.ksteps_per_split;
   if (kend > p.ksteps_total) kend = p.ksteps_total;
+  if (PIPE == 2 && p.stagger > 0 && blockIdx.x < 256 && gridDim.x > 256) {
+    // One workgroup per CU and identical tiles: every CU of an XCD reaches its epilogue at the same
+    // moment and the 32 x 128 KB of C stores share that XCD's write path (7.4 us per tile with the
+    // matrix cores idle, measured with in-kernel stamps).  Spreading the start times inside the XCD
+    // once lets each CU's burst run alone; the offsets persist over the following rounds.
+    const int n = ((blockIdx.x >> 3) & 31) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  }
+#define DTP_STAMP(i) if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
+  if (p.stamps && tid == 0)
+    p.stamps[(size_t)blockIdx.x * 8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                       ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  DTP_STAMP(1)
 
   // ---------------- staging set-up (per-lane source pointers, fixed over the K loop)
   const int srow = tid >> 3;
@@ -390,6 +405,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     if (grp == 1) __builtin_amdgcn_s_barrier();    // stagger the second group of wave rows by one barrier
     __builtin_amdgcn_sched_barrier(0);
 
+    DTP_STAMP(2)
     int t = kbeg;
     for (; t < kend; t += 2) {
       // ---- K-tile t (dbuf 0)
@@ -418,6 +434,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       issue_A(I0{}, I1{}, t + 3);                             // P8
       DTP_PHASE_SYNC_IN(); DTP_MMA(1, 0, b0f) DTP_PHASE_SYNC_OUT();
     }
+    DTP_STAMP(3)
     if (grp == 0) __builtin_amdgcn_s_barrier();    // pair the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain (dummy) DMA before the C image reuses LDS
 #undef DTP_PHASE_SYNC_IN
@@ -490,42 +507,76 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   }
 
   __syncthreads();   // all waves finished reading the staging buffers
+  DTP_STAMP(5)
   {
     const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     const unsigned long long seed = (p.drop_p > 0.f && p.seed_ptr) ? p.seed + *p.seed_ptr : p.seed;
+    // all bias values of this lane in ONE batch of 16-byte loads (Ncols % 8 == 0 on this path, so a
+    // 4-channel group is entirely inside or outside): loading them per j, right before their use,
+    // cost one exposed global-load latency per j — 5 us of an 8-phase tile's 7.5 us epilogue
+    f32x4_t bvv[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int nl = wn * WN + j * 16 + cq;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+      const int n = n0 + wn * WN + j * 16 + cq;
+      bvv[j] = (p.bias && n < p.Ncols) ? *(const f32x4_t*)(p.bias + n) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.drop_p > 0.f) {          // kernel-uniform: classifier layers with dropout, generic path
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (n0 + nl + e < p.Ncols) bv[e] = p.bias[n0 + nl + e];
-      }
+      for (int j = 0; j < NI; ++j) {
+        const int nl = wn * WN + j * 16 + cq;
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int pl = wm * WM + i * 16 + prow;
-        float v[4];
+        for (int i = 0; i < MI; ++i) {
+          const int pl = wm * WM + i * 16 + prow;
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[i][j][e] + bv[e];
-          if (p.relu) x = fmaxf(x, 0.f);
-          if (p.drop_p > 0.f) {
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[i][j][e] + bvv[j][e];
+            if (p.relu) x = fmaxf(x, 0.f);
             const uint64_t idx = (uint64_t)(m0 + pl) * (uint64_t)p.Ncols + (uint64_t)(n0 + nl + e);
-            x = rng_uniform(seed, idx) >= p.drop_p ? x * keep_scale : 0.f;
+            v[e] = rng_uniform(seed, idx) >= p.drop_p ? x * keep_scale : 0.f;
           }
-          v[e] = x;
+          u32x2_t pk;
+          pk[0] = pack_bf16x2(v[0], v[1]);
+          pk[1] = pack_bf16x2(v[2], v[3]);
+          const int q = nl >> 3;
+          const int addr = pl * (BN * 2) + ((q ^ (pl & 7)) << 4) + ((nl >> 2) & 1) * 8;
+          *(u32x2_t*)(smem + addr) = pk;
         }
-        u32x2_t pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
-        const int q = nl >> 3;
-        const int addr = pl * (BN * 2) + ((q ^ (pl & 7)) << 4) + ((nl >> 2) & 1) * 8;
-        *(u32x2_t*)(smem + addr) = pk;
       }
+    } else {
+      // Fast path (every convolution): 128 accumulator values per lane at one wave-instruction per
+      // 4 cycles made this phase VALU-bound (4.5 us of a 256x256 tile).  Vector adds (v_pk_add_f32),
+      // one v_cvt_pk_bf16_f32 per pair, and ReLU AFTER the rounding as a packed signed-16-bit max
+      // on the bf16 bit patterns (negative floats are negative int16s; round(relu(x)) ==
+      // relu(round(x))), with the ReLU switch hoisted out of the loops.
+      auto body = [&](auto relu_tag) {
+        constexpr bool RELU = decltype(relu_tag)::value;
+        typedef short s16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int nl = wn * WN + j * 16 + cq;
+          const int q = nl >> 3, sub = ((nl >> 2) & 1) * 8;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int pl = wm * WM + i * 16 + prow;
+            const f32x4_t a = acc[i][j] + bvv[j];
+            // (scalars, not pk[h] in a loop: hipcc folded the subscripted form into pk[1] = pk[0])
+            uint32_t lo = pack_bf16x2(a[0], a[1]), hi = pack_bf16x2(a[2], a[3]);
+            if (RELU) {
+              lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, lo), (s16x2_t){0, 0}));
+              hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, hi), (s16x2_t){0, 0}));
+            }
+            const u32x2_t pk = {lo, hi};
+            *(u32x2_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4) + sub) = pk;
+          }
+        }
+      };
+      if (p.relu) body(std::true_type{});
+      else body(std::false_type{});
     }
   }
   __syncthreads();
+  DTP_STAMP(6)
   {
     constexpr int CPR = BN / 8;                 // 16-B chunks per C row
     constexpr int TOTAL = BM * CPR;
@@ -578,6 +629,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         }
       }
     }
+    DTP_STAMP(4)
     if (p.colsum_part) {   // kernel-uniform
       // T % CPR == 0: a thread keeps the same 8-column chunk q for all its rows; fold the T/CPR
       // row-groups through LDS (the C image is dead after the barrier), one partial row per tile
@@ -668,6 +720,10 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.dq_a = dq_a; p.dq_b = dq_b;
   static const int k_order_env = std::getenv("DTP_IGEMM_KORDER") ? std::atoi(std::getenv("DTP_IGEMM_KORDER")) : 1;
   p.k_order = k_order_env;
+  static const int stagger_env = std::getenv("DTP_IGEMM_STAGGER") ? std::atoi(std::getenv("DTP_IGEMM_STAGGER")) : 0;
+  p.stagger = stagger_env;
+  p.stamps = nullptr;
+  if (const char* e = std::getenv("DTP_IGEMM_STAMPS")) p.stamps = (unsigned long long*)std::strtoull(e, nullptr, 0);
   if (fp8 && (!dq_a || !dq_b)) return -19;
   p.ksteps_total = taps * (C >> (fp8 ? 7 : 6));
   if (nsplit < 1) nsplit = 1;
