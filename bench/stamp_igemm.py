@@ -19,8 +19,17 @@ x = torch.randn(N_IMG, HW, HW, C, device="cuda").to(BF16)
 w = (torch.randn(Co, 9 * C, device="cuda") * (2.0 / (9 * C)) ** 0.5).to(BF16)
 b = torch.zeros(Co, device="cuda")
 k._overrides["igemm"] = lambda M_, Nc, ks: (16, 1)
-for _ in range(3):
-    k.conv3x3_fprop(x, w, b, True)
+MODE = os.environ.get("MODE", "fprop")
+if MODE == "fprop":
+    for _ in range(3):
+        k.conv3x3_fprop(x, w, b, True)
+else:
+    # data gradient of a Co -> C convolution: output has C channels... use C == Co shapes
+    dy = (torch.randn(N_IMG, HW, HW, Co, device="cuda") * 0.1).to(BF16)
+    wd = k.conv_weight_to_dgrad(w, Co, C)
+    ymask, bits = k.conv3x3_fprop(x, (torch.randn(C, 9 * C, device="cuda") * 0.03).to(BF16), None, True, want_bits=True) if C == Co else (None, None)
+    for _ in range(3):
+        k.conv3x3_dgrad(dy, wd, mask_src=ymask, mask_bits=bits if MODE == "dgrad_bits" else None)
 torch.cuda.synchronize()
 st = stamps.view(tiles, 8).cpu()
 hw = st[:, 0]

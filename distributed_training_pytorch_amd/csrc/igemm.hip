@@ -581,21 +581,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     constexpr int CPR = BN / 8;                 // 16-B chunks per C row
     constexpr int TOTAL = BM * CPR;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int id = tid; id < TOTAL; id += T) {
-      const int pl = id / CPR;
-      const int q = id - pl * CPR;
-      const int m = m0 + pl, n = n0 + q * 8;
-      if (m >= p.M || n >= p.Ncols) continue;
+    // T % CPR == 0: a lane keeps its 8-column chunk q and walks rows pl0, pl0 + G, ...
+    constexpr int G = T / CPR;
+    constexpr int ITER = TOTAL / T;
+    static_assert(T % CPR == 0 && TOTAL % T == 0, "store loop geometry");
+    const int q = tid % CPR, pl0 = tid / CPR;
+    const int n = n0 + q * 8;
+    const bool n_ok = n < p.Ncols;
+    // 1-bit masks of ALL this lane's chunks in one batch of byte loads, issued before the first
+    // LDS read: one exposed load latency per tile instead of one per row (the masked store loop
+    // was 10-12 us of a 256x256 data-gradient tile, in-kernel stamps)
+    uint32_t mb[ITER];
+    if (p.mask_bits) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int m = m0 + pl0 + it * G;
+        mb[it] = (n_ok && m < p.M) ? p.mask_bits[((size_t)m * p.ldo + n) >> 3] : 0u;
+      }
+    }
+    const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int pl = pl0 + it * G;
+      const int m = m0 + pl;
+      if (!n_ok || m >= p.M) continue;
       u32x4_t v = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
       const size_t goff = ((size_t)m * p.ldo + n) * 2;
       if (p.mask_bits) {
-        const uint32_t mb = p.mask_bits[goff >> 4];       // 8 elements = 16 output bytes per mask byte
+        if (unit_scale) {
+          // keep / clear each bf16 by AND with a mask built from two sign-extended bit extracts
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t vw = v[e];
-          float lo = ((mb >> (2 * e)) & 1u) ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
-          float hi = ((mb >> (2 * e + 1)) & 1u) ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
-          v[e] = pack_bf16x2(lo, hi);
+          for (int e = 0; e < 4; ++e) {
+            const int s0 = (int)(mb[it] << (31 - 2 * e)) >> 31;        // bit 2e   -> 0 / ~0
+            const int s1 = (int)(mb[it] << (30 - 2 * e)) >> 31;        // bit 2e+1 -> 0 / ~0
+            v[e] &= ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 & 0xFFFF0000u);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t vw = v[e];
+            float lo = ((mb[it] >> (2 * e)) & 1u) ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+            float hi = ((mb[it] >> (2 * e + 1)) & 1u) ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+            v[e] = pack_bf16x2(lo, hi);
+          }
         }
       } else if (p.mask_src) {
         const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
@@ -633,11 +661,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     if (p.colsum_part) {   // kernel-uniform
       // T % CPR == 0: a thread keeps the same 8-column chunk q for all its rows; fold the T/CPR
       // row-groups through LDS (the C image is dead after the barrier), one partial row per tile
-      constexpr int G = T / CPR;
-      static_assert(T % CPR == 0 && BN <= T, "colsum epilogue geometry");
+      static_assert(BN <= T, "colsum epilogue geometry");
       __syncthreads();
       float* red = (float*)smem;
-      const int q = tid % CPR, g = tid / CPR;
+      const int g = pl0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[g * BN + q * 8 + e] = cs[e];
       __syncthreads();
