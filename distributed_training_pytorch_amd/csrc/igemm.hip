@@ -52,7 +52,6 @@ struct IgemmParams {
   int ksteps_per_split;
   int tiles_m, tiles_n;
   int k_order;            // 3x3 reduction order: 0 = tap-major (tap, channel chunk), 1 = chunk-major (chunk, tap)
-  int stagger;            // PIPE == 2: first-round workgroup on CU slot j of its XCD starts j * stagger * 512 cycles late
   unsigned long long* stamps;   // DEBUG (DTP_IGEMM_STAMPS): per workgroup {hw_id|xcc, t_entry, t_loop, t_loop_end, t_exit}
 };
 
@@ -100,14 +99,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   const int kbeg = blockIdx.y * p.ksteps_per_split;
   int kend = kbeg + p.ksteps_per_split;
   if (kend > p.ksteps_total) kend = p.ksteps_total;
-  if (PIPE == 2 && p.stagger > 0 && blockIdx.x < 256 && gridDim.x > 256) {
-    // One workgroup per CU and identical tiles: every CU of an XCD reaches its epilogue at the same
-    // moment and the 32 x 128 KB of C stores share that XCD's write path (7.4 us per tile with the
-    // matrix cores idle, measured with in-kernel stamps).  Spreading the start times inside the XCD
-    // once lets each CU's burst run alone; the offsets persist over the following rounds.
-    const int n = ((blockIdx.x >> 3) & 31) * p.stagger;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-  }
 #define DTP_STAMP(i) if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
   if (p.stamps && tid == 0)
     p.stamps[(size_t)blockIdx.x * 8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
@@ -120,26 +111,36 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   const int lch = pch ^ ((srow >> 1) & 7);   // logical 16-B chunk this lane fetches
   const char* aptr[AP];
   unsigned amask[AP];
+  if (TAPS9) {
+    // (h, w) of this lane's first row by two integer divisions, of its other rows (RP pixels further
+    // each) incrementally; the 9-bit tap-validity mask is the outer product of 3 row bits and 3
+    // column bits.  (Dividing per row and testing per tap was ~900 VALU instructions per wave:
+    // most of the 3.8 us prologue of a 256x256 tile, in-kernel stamps.)
+    const int hw = p.H * p.W;
+    const int step_h = RP / p.W, step_w = RP - step_h * p.W;       // uniform
+    const int mfirst = m0 + srow;
+    const int rem = mfirst % hw;
+    int h = rem / p.W;
+    int w = rem - h * p.W;
 #pragma unroll
-  for (int i = 0; i < AP; ++i) {
-    const int m = m0 + srow + i * RP;
-    const bool inb = m < p.M;
-    if (TAPS9) {
-      const int hw = p.H * p.W;
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int h = rem / p.W;
-      const int w = rem - h * p.W;
-      unsigned mk = 0;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-        if (inb && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) mk |= 1u << t;
-      }
-      amask[i] = mk;
+    for (int i = 0; i < AP; ++i) {
+      const int m = mfirst + i * RP;
+      const unsigned colbits = (w > 0 ? 1u : 0u) | 2u | (w < p.W - 1 ? 4u : 0u);
+      unsigned mk = colbits << 3;
+      if (h > 0) mk |= colbits;
+      if (h < p.H - 1) mk |= colbits << 6;
+      amask[i] = m < p.M ? mk : 0u;
       aptr[i] = p.A + ((size_t)m * p.C + lch * 8) * 2;
-    } else {
-      amask[i] = inb ? 1u : 0u;
+      w += step_w;
+      h += step_h;
+      if (w >= p.W) { w -= p.W; ++h; }
+      while (h >= p.H) h -= p.H;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int m = m0 + srow + i * RP;
+      amask[i] = m < p.M ? 1u : 0u;
       aptr[i] = p.A + (size_t)m * p.lda * ES + lch * 16;
     }
   }
@@ -747,8 +748,6 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.dq_a = dq_a; p.dq_b = dq_b;
   static const int k_order_env = std::getenv("DTP_IGEMM_KORDER") ? std::atoi(std::getenv("DTP_IGEMM_KORDER")) : 1;
   p.k_order = k_order_env;
-  static const int stagger_env = std::getenv("DTP_IGEMM_STAGGER") ? std::atoi(std::getenv("DTP_IGEMM_STAGGER")) : 0;
-  p.stagger = stagger_env;
   p.stamps = nullptr;
   if (const char* e = std::getenv("DTP_IGEMM_STAMPS")) p.stamps = (unsigned long long*)std::strtoull(e, nullptr, 0);
   if (fp8 && (!dq_a || !dq_b)) return -19;
