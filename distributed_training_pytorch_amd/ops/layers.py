@@ -500,9 +500,7 @@ class _LinearDerived(object):
         the native weight layout; ``batch=None`` asks whether the layer ever needs its W^T."""
         ok = (LINEAR_DGRAD_TT and not self.input_is_relu_out and self.out_features % 64 == 0
               and self.in_features % 8 == 0 and self.in_features * self.out_features >= (1 << 24))
-        if batch is None:
-            return ok
-        return ok and batch % 8 == 0
+        return ok       # any batch: dY^T is zero-padded to 8 columns and only ``batch`` output rows are stored
 
 
 class Linear(_LinearDerived, FusedLayer):
