@@ -320,6 +320,46 @@ def test_relu_bitmask_model_gradients_bit_identical():
         K._overrides.pop("igemm", None)
 
 
+def test_no_uninitialised_reads_with_poisoned_allocator():
+    """Every free block of the caching allocator (large and small pools) and every persistent
+    workspace is filled with NaN before each step: a kernel that consumes memory neither it nor its
+    producer wrote (a split-K slab of an empty split, a partial-sum row past the grid, a padded
+    column) would turn the loss or a gradient into NaN."""
+    from distributed_training_pytorch_amd import _lib
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+
+    def poison():
+        big = torch.full((256 * 1024 * 1024 // 4,), float("nan"), device="cuda")
+        mids = [torch.full((sz // 4,), float("nan"), device="cuda") for sz in (1 << 20, 4 << 20, 16 << 20) for _ in range(6)]
+        small = [torch.full((16 * 1024,), float("nan"), device="cuda") for _ in range(1500)]
+        for key, t in _lib.workspace._bufs.items():
+            if key[0] != "zero_page" and t.is_floating_point():
+                t.fill_(float("nan"))
+        torch.cuda.synchronize()
+        del big, mids, small
+
+    for size, batch in ((32, 4), (64, 8)):
+        torch.manual_seed(23)
+        m = VGG16(3, 3, True, dropout=0.3).to("cuda").train()
+        o = FusedSGD(m, lr=0.002, momentum=0.9, weight_decay=1e-4)
+        c = SoftmaxCrossEntropy()
+        a = m.param_arena
+        for step in range(3):
+            x = torch.randn(batch, 3, size, size, device="cuda")
+            y = torch.randint(0, 3, (batch,), device="cuda")
+            poison()
+            o.zero_grad()
+            loss = c(m(x), y)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(loss.detach())), (size, step)
+            assert bool(torch.isfinite(a.flat_grad.float()).all()), (size, step)
+            o.step()
+        assert bool(torch.isfinite(a.flat_master).all())
+
+
 def test_hip_graph_step_matches_eager_and_redraws_dropout():
     """GraphedTrainStep: (a) with dropout off, N graph replays == N eager steps bit for bit;
     (b) with dropout on, replays draw different masks (device-resident seed) and still train;
