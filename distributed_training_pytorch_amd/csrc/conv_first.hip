@@ -329,15 +329,27 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
 // out_w[co][k] (k < K) and out_b[co] (k == 27) = beta*old + sum_g partial[g][co][k]
 __global__ void conv1_wgrad_reduce_kernel(const float* __restrict__ partial, int G, int K, void* __restrict__ out_w,
                                           void* __restrict__ out_b, int out_fp32, float beta_w, float beta_b) {
-  __shared__ float red[4][64];
-  const int ol = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + ol;          // 0..2047 = co*32 + k
-  float s = 0.f;
-  for (int g = grp; g < G; g += 4) s += partial[(size_t)g * 2048 + o];
-  red[grp][ol] = s;
+  // 16 outputs x 16 slab groups per workgroup, four independent accumulators per thread, fixed-order
+  // fold through LDS (this kernel is the tail of backward: one accumulator walking G/4 slabs per
+  // thread was ~80 us of exposed load latency)
+  __shared__ float red[16][16];
+  const int ol = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + ol;          // 0..2047 = co*32 + k
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = grp;
+  for (; g + 48 < G; g += 64) {
+    s0 += partial[(size_t)g * 2048 + o];
+    s1 += partial[(size_t)(g + 16) * 2048 + o];
+    s2 += partial[(size_t)(g + 32) * 2048 + o];
+    s3 += partial[(size_t)(g + 48) * 2048 + o];
+  }
+  for (; g < G; g += 16) s0 += partial[(size_t)g * 2048 + o];
+  red[grp][ol] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (grp != 0) return;
-  s = (red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol]);
+  float s = red[0][ol];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][ol];
   const int co = o >> 5, k = o & 31;
   void* dst; int idx; float beta;
   if (k < K) { dst = out_w; idx = co * K + k; beta = beta_w; }
@@ -395,7 +407,7 @@ extern "C" int dtp_conv1_wgrad(const void* x, int in_kind, const void* dy, void*
   else if (in_kind == 1) hipLaunchKernelGGL(conv1_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, p);
   else if (in_kind == 2) hipLaunchKernelGGL(conv1_wgrad_kernel<uint8_t>, dim3(grid), dim3(256), lds, s, p);
   else return -11;
-  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(32), dim3(256), 0, s, partial, grid, 9 * Cin, out_w, out_b,
+  hipLaunchKernelGGL(conv1_wgrad_reduce_kernel, dim3(128), dim3(256), 0, s, partial, grid, 9 * Cin, out_w, out_b,
                      out_fp32, beta_w, beta_b);
   return DTP_CHECK_LAUNCH();
 }

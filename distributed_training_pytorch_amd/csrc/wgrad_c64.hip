@@ -168,21 +168,35 @@ __global__ __launch_bounds__(COUT * 4) void wgrad_c64_kernel(const WgC64Params p
 }
 
 // out = beta*out + sum_g partial[g]   (total % 4 == 0)
-__global__ void wgrad_c64_reduce_kernel(const float* __restrict__ partial, int G, size_t total,
-                                        void* __restrict__ out, int out_fp32, float beta) {
+__global__ __launch_bounds__(256) void wgrad_c64_reduce_kernel(const float* __restrict__ partial, int G, size_t total,
+                                                               void* __restrict__ out, int out_fp32, float beta) {
+  // 32 float4 columns x 8 slab groups per workgroup: thread (li, gg) sums slabs g = gg, gg+8, ...
+  // (four independent accumulators), the 8 group sums are folded through LDS in a fixed order.
+  // (One thread per column walking all <= 512 slabs ran 36-72 workgroups of pure load latency:
+  // 40 us alone, ~200 us next to the data-gradient stream.)
+  __shared__ f32x4_t red[8][32];
   const size_t nvec = total >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-       i += (size_t)gridDim.x * blockDim.x) {
+  const int li = threadIdx.x & 31, gg = threadIdx.x >> 5;
+  {
+    const size_t i = (size_t)blockIdx.x * 32 + li;
     f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
-    int g = 0;
-    for (; g + 3 < G; g += 4) {
-      v0 += *(const f32x4_t*)(partial + (size_t)g * total + (i << 2));
-      v1 += *(const f32x4_t*)(partial + (size_t)(g + 1) * total + (i << 2));
-      v2 += *(const f32x4_t*)(partial + (size_t)(g + 2) * total + (i << 2));
-      v3 += *(const f32x4_t*)(partial + (size_t)(g + 3) * total + (i << 2));
+    if (i < nvec) {
+      const float* base = partial + (i << 2);
+      int g = gg;
+      for (; g + 24 < G; g += 32) {
+        v0 += *(const f32x4_t*)(base + (size_t)g * total);
+        v1 += *(const f32x4_t*)(base + (size_t)(g + 8) * total);
+        v2 += *(const f32x4_t*)(base + (size_t)(g + 16) * total);
+        v3 += *(const f32x4_t*)(base + (size_t)(g + 24) * total);
+      }
+      for (; g < G; g += 8) v0 += *(const f32x4_t*)(base + (size_t)g * total);
     }
-    for (; g < G; ++g) v0 += *(const f32x4_t*)(partial + (size_t)g * total + (i << 2));
-    f32x4_t v = (v0 + v1) + (v2 + v3);
+    red[gg][li] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (gg != 0 || i >= nvec) return;
+    f32x4_t v = red[0][li];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += red[k][li];
     if (out_fp32) {
       float* d = (float*)out + (i << 2);
       if (beta != 0.f) v += *(const f32x4_t*)d * beta;
@@ -231,7 +245,7 @@ extern "C" int dtp_wgrad_c64(const void* dY, const void* X, void* out, float* pa
   }
   if (DTP_CHECK_LAUNCH() != 0) return -1;
   const size_t total = (size_t)Cout * 576;
-  int blocks = (int)((total / 4 + 255) / 256);
+  int blocks = (int)((total / 4 + 31) / 32);
   hipLaunchKernelGGL(wgrad_c64_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, grid, total, out,
                      out_fp32, beta);
   return DTP_CHECK_LAUNCH();
