@@ -509,6 +509,8 @@ def avgpool_flatten_fwd(x, OH=7, OW=7):
     _need(x, BF16, "x")
     N, H, W, C = x.shape
     y = torch.empty((N, C * OH * OW), dtype=BF16, device=x.device)
+    if (H, W) == (OH, OW):       # 224x224 input: the pool is the identity, only the NHWC -> CHW-flatten order changes
+        return transpose_bf16(x, y, H * W, C, C, H * W, batch=N, in_bs=H * W * C, out_bs=C * H * W)
     check(_lib.hip().dtp_avgpool_flatten_fwd(ptr(x), ptr(y), N, H, W, C, OH, OW, stream()), "avgpool_fwd")
     return y
 
@@ -518,6 +520,8 @@ def avgpool_flatten_bwd(dy, N, H, W, C, OH=7, OW=7):
     if dy.numel() != N * C * OH * OW:
         raise ValueError("avgpool_flatten_bwd: dy size")
     dx = torch.empty((N, H, W, C), dtype=BF16, device=dy.device)
+    if (H, W) == (OH, OW):       # identity pool: a batched [C][HW] -> [HW][C] transpose (was 104 us of div/mod + 2-byte gathers)
+        return transpose_bf16(dy, dx, C, H * W, H * W, C, batch=N, in_bs=C * H * W, out_bs=H * W * C)
     check(_lib.hip().dtp_avgpool_flatten_bwd(ptr(dy), ptr(dx), N, H, W, C, OH, OW, stream()), "avgpool_bwd")
     return dx
 
