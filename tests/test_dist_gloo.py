@@ -22,10 +22,13 @@ def _launch(scenario, out, nproc=2, timeout=600, extra_env=None):
                           timeout=timeout)
 
 
-def test_bucketed_reducer_equals_large_batch_gloo(tmp_path):
-    r = _launch("reducer", tmp_path)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_reducer_equals_large_batch_gloo(tmp_path, world):
+    """world 4 rehearses the rank counts of the 4-/8-GPU runs the driver launches (same bucket
+    planning, broadcast, averaging and no_sync logic; only the transport differs on GPUs)."""
+    r = _launch("reducer", tmp_path, nproc=world)
     assert r.returncode == 0, r.stdout[-4000:]
-    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.0", "ok.1"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % i for i in range(world)]
 
 
 def test_trainer_vgg16_synthetic_gloo_world2(tmp_path):
