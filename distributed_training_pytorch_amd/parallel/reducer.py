@@ -23,6 +23,7 @@ This module re-implements that contract, transport-agnostic:
     one fused scale per bucket.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -82,6 +83,9 @@ class _Bucket(object):
         self.comm_buf = None
 
 
+_GLOO_STAGE_HOST = os.environ.get("DTP_GLOO_STAGE_HOST", "1") == "1"
+
+
 class TorchPGTransport(object):
     """All-reduce through a ``torch.distributed`` process group (gloo / RCCL)."""
 
@@ -95,18 +99,33 @@ class TorchPGTransport(object):
             return None
         if self.backend == "nccl":
             return ("avg", dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        if flat.is_cuda and _GLOO_STAGE_HOST:
+            # gloo on GPU tensors (development / one-GPU rehearsals only): reduce a host copy.  gloo's
+            # own device path hung or corrupted buffers intermittently with 4 ranks sharing one GPU.
+            host = flat.to("cpu")
+            return ("host", (dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), host))
         return ("sum", dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def wait(self, handle, flat):
         if handle is None:
             return
         kind, work = handle
+        if kind == "host":
+            work, host = work
+            work.wait()
+            flat.copy_(host.mul_(1.0 / self.world), non_blocking=False)
+            return
         work.wait()
         if kind == "sum":
             flat.mul_(1.0 / self.world)
 
     def broadcast(self, flat, src=0):
         if self.world > 1:
+            if self.backend != "nccl" and flat.is_cuda and _GLOO_STAGE_HOST:
+                host = flat.to("cpu")
+                dist.broadcast(host, src=src, group=self.pg)
+                flat.copy_(host)
+                return
             dist.broadcast(flat, src=src, group=self.pg)
 
 

@@ -54,6 +54,8 @@ def scenario_gpu_shared(out):
     net = TinyNet().to(dev)
     dp = DataParallel(net, bucket_cap_mb=0.05, first_bucket_mb=0.01)
     assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
+    torch.cuda.synchronize()
+    assert _allclose_across_ranks(net.param_arena.flat_master.cpu()), "broadcast of initial parameters failed"
     opt = FusedSGD(net, lr=0.05, momentum=0.9)
     crit = SoftmaxCrossEntropy()
     g = torch.Generator().manual_seed(7)
@@ -70,6 +72,8 @@ def scenario_gpu_shared(out):
         gsum = a.flat_grad.float().cpu()
         assert _allclose_across_ranks(gsum), "step %d: averaged gradients differ across ranks" % it
         opt.step()
+        torch.cuda.synchronize()
+        assert _allclose_across_ranks(a.flat_master.cpu()), "step %d: parameters diverged across ranks" % it
         losses.append(float(loss.detach()))
     torch.cuda.synchronize()
     assert all(l == l for l in losses), losses

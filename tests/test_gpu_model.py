@@ -523,8 +523,8 @@ def test_uint8_ingest_matches_float_input_on_gpu():
     assert cos > 0.99, cos
 
 
-@pytest.mark.parametrize("transport", ["torch", "auto"])
-def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport):
+@pytest.mark.parametrize("transport,world", [("torch", 2), ("auto", 2), ("torch", 4)])
+def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport, world):
     """Multi-process GPU path on a one-GPU box: two ranks share cuda:0, process group over gloo,
     a small user-defined FusedModel, six optimizer steps; gradients and parameters must be
     identical across ranks after every all-reduce (tests/dist_worker.py::scenario_gpu_shared).
@@ -537,10 +537,10 @@ def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DTP_TRANSPORT=transport, DTP_NATIVE_INIT_TIMEOUT_S="15", OMP_NUM_THREADS="2",
                DTP_PG_TIMEOUT_S="60")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(29750 + os.getpid() % 100),
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(29750 + os.getpid() % 100 + world),
            os.path.join(root, "tests", "dist_worker.py"), "gpu_shared", str(tmp_path)]
     r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                       timeout=110)
+                       timeout=150)
     assert r.returncode == 0, r.stdout[-4000:]
-    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.0", "ok.1"]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % i for i in range(world)]
