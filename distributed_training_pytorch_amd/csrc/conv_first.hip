@@ -126,26 +126,27 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const Conv1Params p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(lW + (j * 16) * 64 + foff);
   const int cq = (lane >> 4) * 4;
+  // bias as the MFMA's C operand (one batch of 16-byte loads issued before the first use), ReLU after
+  // the rounding as a packed signed-16-bit max on the bf16 bit patterns (as in igemm.hip's epilogue)
+  f32x4_t bvv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bvv[j] = p.bias ? *(const f32x4_t*)(p.bias + j * 16 + cq) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  const bool relu = p.relu != 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float bv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[e] = p.bias ? p.bias[j * 16 + cq + e] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc, 0, 0, 0);
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = acc[e] + bv[e];
-        if (p.relu) o[e] = fmaxf(o[e], 0.f);
+      const f32x4_t acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], bvv[j], 0, 0, 0);
+      uint32_t lo = pack_bf16x2(acc[0], acc[1]), hi = pack_bf16x2(acc[2], acc[3]);
+      if (relu) {
+        lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, lo), (s16x2_t){0, 0}));
+        hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, hi), (s16x2_t){0, 0}));
       }
       const int pl = wave * 64 + i * 16 + fr;       // pixel in tile
       const int nl = j * 16 + cq;                   // first of 4 channels
-      u32x2_t pk;
-      pk[0] = pack_bf16x2(o[0], o[1]);
-      pk[1] = pack_bf16x2(o[2], o[3]);
+      const u32x2_t pk = {lo, hi};
       *(u32x2_t*)(lC + pl * 128 + (((nl >> 3) ^ (pl & 7)) << 4) + ((nl >> 2) & 1) * 8) = pk;
     }
   }
@@ -263,23 +264,25 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
       for (int i = 0; i < 4; ++i) xf[i] = *(const bf16x8_t*)(lA + (wave * 64 + i * 16) * 64 + foff);
 #pragma unroll
       for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(lW + (j * 16) * 64 + foff);
+      // same arithmetic as conv1_fprop_kernel (bias is the MFMA's C operand) so the recomputed sign
+      // is bit-identical to the stored activation's; all bias loads in one batch
+      f32x4_t bvv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bvv[j] = p.mask_bias ? *(const f32x4_t*)(p.mask_bias + j * 16 + cq) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = p.mask_bias ? p.mask_bias[j * 16 + cq + e] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f32x4_t y = {0.f, 0.f, 0.f, 0.f};
-          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], y, 0, 0, 0);
+          const f32x4_t y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], bvv[j], 0, 0, 0);
           const int pl = wave * 64 + i * 16 + fr;       // pixel (dY image row)
           const int nl = j * 16 + cq;                   // first of 4 channels
           const int rsw = (((pl >> 1) & 1) | (((pl >> 3) & 1) << 1)) << 1;
           u32x2_t* dp = (u32x2_t*)(lD + pl * 128 + ((((nl >> 3)) ^ rsw) << 4) + ((nl >> 2) & 1) * 8);
           u32x2_t d = *dp;
           // the forward kernel stores bf16(relu(y + b)): active <=> that bf16 value is > 0
-          const bool a0 = bf16_to_f32(f32_to_bf16(y[0] + bv[0])) > 0.f, a1 = bf16_to_f32(f32_to_bf16(y[1] + bv[1])) > 0.f;
-          const bool a2 = bf16_to_f32(f32_to_bf16(y[2] + bv[2])) > 0.f, a3 = bf16_to_f32(f32_to_bf16(y[3] + bv[3])) > 0.f;
+          const bool a0 = bf16_to_f32(f32_to_bf16(y[0])) > 0.f, a1 = bf16_to_f32(f32_to_bf16(y[1])) > 0.f;
+          const bool a2 = bf16_to_f32(f32_to_bf16(y[2])) > 0.f, a3 = bf16_to_f32(f32_to_bf16(y[3])) > 0.f;
           d[0] = (a0 ? (d[0] & 0xFFFFu) : 0u) | (a1 ? (d[0] & 0xFFFF0000u) : 0u);
           d[1] = (a2 ? (d[1] & 0xFFFFu) : 0u) | (a3 ? (d[1] & 0xFFFF0000u) : 0u);
           *dp = d;
