@@ -1,14 +1,21 @@
 """Headline benchmark: VGG16 bf16 224x224 training images/sec (whole job), synthetic data,
 random-init weights, on N MI355X of one node (BASELINE.json "metric").
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py                                  # 1 GPU
+  python bench.py --gpus 8                         # self-launch: 8 fresh worker processes, one per GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W          # the driver's launch
 
-One timed step = zero_grad + ingest (NCHW f32 -> NHWC bf16) + forward + fused softmax-xent +
-backward (weight/bias gradients for all 32 tensors, bucketed RCCL all-reduce overlapped with
-backward when N > 1) + fused SGD-momentum step on fp32 master weights.  Weak scaling: the per-GPU
-batch is fixed.  Rank 0 prints ONE JSON line.
+One timed step = zero_grad + ingest (NCHW f32 -> NHWC bf16, or pinned uint8 host batch -> H2D copy
+-> fused normalisation with ``--data host-u8``) + forward + fused softmax-xent + backward
+(weight/bias gradients for all 32 tensors, bucketed RCCL all-reduce overlapped with backward when
+N > 1) + fused SGD-momentum step on fp32 master weights.  Weak scaling: the per-GPU batch is fixed.
+Rank 0 prints ONE JSON line.
+
+Without WORLD_SIZE in the environment and with --gpus N > 1 this script is its own launcher
+(reference run.sh:9-14 starts the ranks with torchrun): the parent process never touches the GPU
+— it does not import torch — and starts N brand-new workers (distributed_training_pytorch_amd/launch.py),
+relays their output and exits non-zero if any of them does.
 """
 import argparse
 import json
@@ -16,14 +23,10 @@ import os
 import sys
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-
-# Default per-GPU batch 1024 (50 GB of the 288 GB HBM; BASELINE.json config 4): 10,045 img/s on one
+# Default per-GPU batch 1024 (50 GB of the 288 GB HBM; BASELINE.json config 4): ~10,000 img/s on one
 # MI355X vs 9,500 at 256 and 3,995 for stock PyTorch-ROCm at 1024.
 # stock PyTorch-ROCm (MIOpen / hipBLASLt, autocast bf16, channels_last), 1 MI355X, same step, by
 # per-GPU batch (profiles/00_*, 07_*: bench/bench_stock.py); the comparison uses the entry measured
@@ -36,7 +39,7 @@ def stock_img_s(batch):
     return STOCK_1GPU_BF16_IMG_S[keys[-1]], keys[-1]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -46,33 +49,69 @@ def main():
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--grad-dtype", default=os.environ.get("DTP_BENCH_GRAD_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--lr", type=float, default=0.001)
-    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--backend", default=None, help="process-group backend (nccl = RCCL; gloo for rehearsals / CPU)")
+    ap.add_argument("--device", default="auto", choices=["auto", "cuda", "cpu"],
+                    help="cpu: plumbing rehearsal on the PyTorch reference ops (not a benchmark)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (multi-process plumbing on a one-GPU box)")
     ap.add_argument("--grad-accum", type=int, default=1,
                     help="micro-batches per optimizer step (BASELINE config 4): the per-GPU batch is split "
                          "into this many micro-steps, all-reduce only on the last one (no_sync)")
-    args = ap.parse_args()
+    ap.add_argument("--data", default="device", choices=["device", "host-u8"],
+                    help="device: pre-generated device-resident f32 batches; host-u8: uint8 batches in a pinned "
+                         "host ring, H2D copy on the copy stream inside the timed region, normalisation fused "
+                         "into the first convolution (the reference's pinned loader + per-step H2D, main.py:16)")
+    ap.add_argument("--batch-norm", action="store_true", help="VGG16-BN (BASELINE.json config 5)")
+    ap.add_argument("--fp8-classifier", action="store_true", help="linear1/linear2 GEMMs in OCP e4m3 (config 5)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="reduce-scatter + per-bucket sharded SGD + all-gather instead of all-reduce + replicated SGD")
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv):
+    """Parent side of ``python bench.py --gpus N``: no torch import, no GPU call."""
+    from distributed_training_pytorch_amd.launch import spawn_workers
+    return spawn_workers(os.path.abspath(__file__), argv, args.gpus)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, argv))
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
     if os.environ.get("DTP_BENCH_DUMP_AFTER"):      # debugging aid: dump every thread's stack and exit
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["DTP_BENCH_DUMP_AFTER"]), exit=True)
+
+    import torch
+    import torch.distributed as dist
+    from distributed_training_pytorch_amd.parallel import env as penv
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (see module docstring)")
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    on_gpu = args.device == "cuda" or (args.device == "auto" and torch.cuda.is_available())
+    backend = args.backend or ("nccl" if on_gpu else "gloo")
+    applied_env = penv.apply_rccl_env_defaults()
+    if on_gpu:
+        if args.share_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1)))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        import datetime
+        kw = dict(timeout=datetime.timedelta(seconds=float(os.environ.get("DTP_PG_TIMEOUT_S", "600"))))
+        if backend == "nccl":
+            kw["device_id"] = dev
+        dist.init_process_group(backend, **kw)
 
     from distributed_training_pytorch_amd.data.synthetic import DeviceBatchSource
     from distributed_training_pytorch_amd.models.vgg16 import VGG16
@@ -81,17 +120,26 @@ def main():
     from distributed_training_pytorch_amd.parallel.data_parallel import DataParallel
 
     torch.manual_seed(0)
-    gdt = torch.bfloat16 if args.grad_dtype == "bf16" else torch.float32
-    model = VGG16(3, args.classes, True, grad_dtype=gdt).to(dev)
+    gdt = torch.bfloat16 if (args.grad_dtype == "bf16" and on_gpu) else torch.float32
+    model = VGG16(3, args.classes, True, grad_dtype=gdt, batch_norm=args.batch_norm,
+                  fp8_classifier=args.fp8_classifier).to(dev)
     opt = FusedSGD(model, lr=args.lr, momentum=0.9, weight_decay=1e-4)
     crit = SoftmaxCrossEntropy()
-    dp = DataParallel(model)
+    dp = DataParallel(model, shard_optimizer=opt if args.shard_optimizer else None)
     dp.train()
     if args.grad_accum < 1 or args.batch_per_gpu % args.grad_accum:
         raise SystemExit("--batch-per-gpu must be a multiple of --grad-accum")
     micro = args.batch_per_gpu // args.grad_accum
-    data = DeviceBatchSource(micro, args.classes, args.image_size, args.image_size,
-                             device=dev, n_distinct=2, seed=rank)
+    if args.data == "host-u8":
+        from distributed_training_pytorch_amd.data.prefetch import PinnedRingSource
+        data = PinnedRingSource(micro, args.classes, args.image_size, args.image_size, device=dev, seed=rank)
+        model.set_input_normalization(*data.normalization)
+        data_desc = ("synthetic (uint8 NCHW batches in a pinned host ring, H2D copy on the copy stream inside the "
+                     "timed region, normalisation fused into conv1; random-init weights)")
+    else:
+        data = DeviceBatchSource(micro, args.classes, args.image_size, args.image_size,
+                                 device=dev, n_distinct=2, seed=rank)
+        data_desc = "synthetic (device-resident f32 NCHW batches, random-init weights)"
 
     def step():
         opt.zero_grad()
@@ -107,58 +155,96 @@ def main():
         return loss
 
     def fence():
-        torch.cuda.synchronize()          # drain compute + gradient-comm streams before the barrier
+        if on_gpu:
+            torch.cuda.synchronize()          # drain compute + gradient-comm streams before the barrier
         if world > 1:
-            if args.backend == "nccl":
+            if backend == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
                 dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     verbose = os.environ.get("DTP_BENCH_VERBOSE") == "1"
     for i in range(args.warmup):
         loss = step()
         if verbose:
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             print("[bench rank %d] warm-up step %d done, loss %.4f" % (rank, i, float(loss.detach())),
                   file=sys.stderr, flush=True)
     fence()
     exposed0 = dp.reducer.exposed_ms_total()
+    wait0 = getattr(data, "wait_ms_total", lambda: 0.0)()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
     exposed = (dp.reducer.exposed_ms_total() - exposed0) / max(1, args.steps)
-    t = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+    data_wait = (getattr(data, "wait_ms_total", lambda: 0.0)() - wait0) / max(1, args.steps)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+    ones = torch.ones(1, device=cdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)          # how many ranks really took part
     dt = float(t.item())
+    ranks_seen = int(round(float(ones.item())))
     final_loss = float(loss.detach().float().item())
+    # self-check of the gradient transport itself: average of (rank + 1) must be (world + 1) / 2
+    tr = dp.reducer.transport
+    probe = torch.full((256,), float(rank + 1), device=dev)
+    tr.wait(tr.launch(probe), probe)
+    if on_gpu:
+        torch.cuda.synchronize()
+    transport_ok = bool(((probe - (world + 1) / 2.0).abs() < 1e-5).all())
     if rank == 0:
         global_batch = args.batch_per_gpu * world
         value = global_batch * args.steps / dt
+        info = getattr(tr, "info", None) or {}
+        plain = not (args.batch_norm or args.fp8_classifier)
         print(json.dumps({
             "metric": "train images/sec (whole node) VGG16 bf16 224px",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": value / (stock_img_s(args.batch_per_gpu)[0] * world),
+            "scaling": "weak",
+            "vs_baseline": (value / (stock_img_s(args.batch_per_gpu)[0] * world)) if (on_gpu and plain) else None,
             "baseline": "stock PyTorch-ROCm bf16 channels_last on 1 MI355X (%.0f img/s at per-GPU batch %d) x "
                         "n_gpus; the reference publishes no numbers" % stock_img_s(args.batch_per_gpu),
-            "dtype": "bf16", "data": "synthetic (device-resident f32 NCHW batches, random-init weights)",
+            "dtype": "bf16" if on_gpu else "fp32 (CPU rehearsal on the reference ops, not a benchmark)",
+            "data": data_desc,
             "final_loss": final_loss,
-            "max_memory_reserved_gb": torch.cuda.max_memory_reserved(dev) / 2 ** 30,
+            "max_memory_reserved_gb": (torch.cuda.max_memory_reserved(dev) / 2 ** 30) if on_gpu else 0.0,
             "allreduce_exposed_ms_per_step": exposed,     # compute stream idle waiting for gradient buckets (rank 0)
-            "config": {"model": "VGG16 (no BN, %d classes, 134M params)" % args.classes,
+            "data_wait_ms_per_step": data_wait,           # host blocked on the input ring (rank 0)
+            "ranks_seen": ranks_seen,
+            "grad_transport": type(tr).__name__,
+            "grad_transport_selfcheck_ok": transport_ok,
+            "native_transport_fell_back": bool(info.get("fell_back", False)),
+            "native_transport_fallback_reason": info.get("reason"),
+            "bucket_mbytes": [round(b["mbytes"], 3) for b in dp.reducer.bucket_summary()],
+            "rccl_env_applied_by_bench": applied_env,
+            "config": {"model": "VGG16 (%s, %d classes, %dM params)" % (
+                           "BN" if args.batch_norm else "no BN", args.classes,
+                           round(sum(p.numel() for p in model.parameters()) / 1e6)),
                        "global_batch": global_batch, "image_size": args.image_size,
                        "seq_len": None, "parallelism": "dp%d" % world,
-                       "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights",
-                       "grad_dtype": args.grad_dtype, "grad_accum": args.grad_accum,
-                       "grad_transport": type(dp.reducer.transport).__name__}}), flush=True)
-    torch.cuda.synchronize()
+                       "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights%s" % (
+                           ", sharded per bucket (reduce-scatter + all-gather)" if dp.reducer.sharded else ""),
+                       "grad_dtype": args.grad_dtype if on_gpu else "fp32", "grad_accum": args.grad_accum,
+                       "fp8_classifier": bool(args.fp8_classifier), "backend": backend,
+                       "grad_transport": type(tr).__name__}}), flush=True)
+    if on_gpu:
+        torch.cuda.synchronize()
+    if hasattr(data, "close"):
+        data.close()
     dp.close()
     if world > 1:
         dist.destroy_process_group()
+    if not transport_ok or ranks_seen != world:
+        raise SystemExit("gradient transport self-check failed (ok=%s, ranks seen %d of %d)"
+                         % (transport_ok, ranks_seen, world))
 
 
 if __name__ == "__main__":

@@ -1,12 +1,13 @@
 """In-tree build of the native libraries with hipcc for gfx950 (cross-compiles without a GPU).
 
   lib/libdtp_hip.so      — all HIP kernels (csrc/*.hip), plain C ABI, no torch headers
-  lib/libdtp_runtime.so  — host runtime (csrc/runtime/*.cpp): RCCL bucket transport, pinned
-                           prefetch ring; links librccl + libamdhip64
+  lib/libdtp_runtime.so  — host runtime (csrc/runtime/*.cpp): RCCL bucket transport + bucket
+                           scheduler (all-reduce and sharded reduce-scatter/optimizer/all-gather),
+                           pinned host ring for the input pipeline; links librccl + libamdhip64
 
-``python -m distributed_training_pytorch_amd._build`` or ``build_all()``.  Objects are rebuilt only
-when their source (or a header) is newer.  The .so files are git-ignored but travel with the
-``gpurun`` snapshot, so GPU boxes never compile.
+``python -m distributed_training_pytorch_amd._build [--clean]`` or ``build_all(clean=...)``.  Without
+``clean`` objects are rebuilt only when their source (or a header) is newer.  The .so files are
+git-ignored but travel with the ``gpurun`` snapshot, so GPU boxes never compile.
 """
 import concurrent.futures
 import glob
@@ -85,13 +86,26 @@ def build_runtime(verbose=False):
     return out
 
 
-def build_all(verbose=False):
+def clean():
+    """Remove every object file and library: the next build compiles everything from source."""
+    import shutil
+    shutil.rmtree(OBJDIR, ignore_errors=True)
+    for name in ("libdtp_hip.so", "libdtp_runtime.so"):
+        try:
+            os.remove(os.path.join(LIBDIR, name))
+        except FileNotFoundError:
+            pass
+
+
+def build_all(verbose=False, clean_first=False):
+    if clean_first:
+        clean()
     a = build_hip(verbose)
     b = build_runtime(verbose)
     return [p for p in (a, b) if p]
 
 
 if __name__ == "__main__":
-    for p in build_all(verbose=True):
+    for p in build_all(verbose=True, clean_first="--clean" in sys.argv[1:]):
         print(p)
     sys.exit(0)

@@ -116,6 +116,52 @@ int dtp_rccl_allreduce_async(void* h, void* buf, size_t count, int dtype_kind, i
   return 0;
 }
 
+// Sharded mode, first half: in-place reduce-scatter (average) of buf[count]; rank r's slice
+// buf[r*S, (r+1)*S), S = count / world, receives the result.  count % world must be 0.
+int dtp_rccl_reduce_scatter_async(void* h, void* buf, size_t count, int dtype_kind, hipStream_t producer_stream) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t || !buf || count == 0 || count % (size_t)t->world != 0) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  const size_t S = count / (size_t)t->world, esz = dtype_kind == 1 ? 2 : 4;
+  if (producer_stream != t->comm_stream) {
+    hipEvent_t ready = t->event();
+    if (!ready) return -3;
+    DTP_HIP(hipEventRecord(ready, producer_stream));
+    DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
+  }
+  DTP_NCCL(ncclReduceScatter(buf, (char*)buf + (size_t)t->rank * S * esz, S, dtype_of(dtype_kind), ncclAvg, t->comm,
+                             t->comm_stream));
+  t->launched += 1;
+  t->bytes += count * esz;
+  return 0;
+}
+
+// Sharded mode, second half: in-place all-gather; every rank contributes its slice of buf[count].
+// ``producer_stream`` may be the null handle meaning "already ordered on the comm stream".
+int dtp_rccl_all_gather_async(void* h, void* buf, size_t count, int dtype_kind, hipStream_t producer_stream,
+                              int on_comm_stream) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t || !buf || count == 0 || count % (size_t)t->world != 0) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  const size_t S = count / (size_t)t->world, esz = dtype_kind == 1 ? 2 : 4;
+  if (!on_comm_stream) {
+    hipEvent_t ready = t->event();
+    if (!ready) return -3;
+    DTP_HIP(hipEventRecord(ready, producer_stream));
+    DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
+  }
+  DTP_NCCL(ncclAllGather((char*)buf + (size_t)t->rank * S * esz, buf, S, dtype_of(dtype_kind), t->comm,
+                         t->comm_stream));
+  t->launched += 1;
+  t->bytes += count * esz;
+  return 0;
+}
+
+void* dtp_rccl_comm_stream(void* h) {
+  auto* t = static_cast<Transport*>(h);
+  return t ? (void*)t->comm_stream : nullptr;
+}
+
 // Make consumer_stream wait for every collective launched so far (no host blocking).
 int dtp_rccl_wait(void* h, hipStream_t consumer_stream) {
   auto* t = static_cast<Transport*>(h);
@@ -186,6 +232,23 @@ struct DtpBucket {
   bool launched;
 };
 
+// Fused flat-arena optimizer kernels of libdtp_hip.so (csrc/optim.hip), handed over as function
+// pointers so that this library does not link against the kernel library.
+typedef int (*dtp_sgd_fn)(float* p, const void* g, int grad_bf16, float* mom, void* lp, size_t n, float lr,
+                          float momentum, float dampening, float wd, float grad_scale, int nesterov, int first_step,
+                          hipStream_t s);
+typedef int (*dtp_adamw_fn)(float* p, const void* g, int grad_bf16, float* m, float* v, void* lp, size_t n, float lr,
+                            float beta1, float beta2, float eps, float wd, float grad_scale, int step, hipStream_t s);
+
+// Sharded mode: what this rank owns of one bucket (all pointers at the start of the OWNED slice),
+// plus the whole bucket's range of the working-weight buffer for the all-gather.
+struct DtpShard {
+  float* master; void* grad; float* s1; float* s2; void* lp;
+  size_t n;           // elements in the owned slice
+  void* wbase;        // bucket range of the working weights (all-gather buffer)
+  size_t wcount;      // = n * world
+};
+
 struct DtpReducer {
   void* transport;
   std::vector<DtpBucket> buckets;
@@ -193,7 +256,37 @@ struct DtpReducer {
   std::vector<char> ready;
   bool require_sync = true;
   unsigned long long passes = 0, launched = 0, duplicate_notifications = 0;
+  // sharded optimizer
+  int opt_kind = 0;                 // 0: all-reduce mode; 1: SGD; 2: AdamW
+  dtp_sgd_fn sgd = nullptr;
+  dtp_adamw_fn adamw = nullptr;
+  std::vector<DtpShard> shards;
+  int wkind = 1;                    // dtype of the working weights (1 = bf16)
+  float hyper[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int iargs[4] = {0, 0, 0, 0};
+  bool pass_armed = false;
 };
+
+// one bucket: all-reduce, or reduce-scatter -> optimizer on the owned slice -> all-gather
+static int launch_bucket(DtpReducer* r, int bi, hipStream_t producer_stream) {
+  DtpBucket& b = r->buckets[bi];
+  if (r->opt_kind == 0)
+    return dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream);
+  if (!r->pass_armed) return -30;      // begin_pass() must precede the first launch of a pass
+  int rc = dtp_rccl_reduce_scatter_async(r->transport, b.ptr, b.count, b.dtype_kind, producer_stream);
+  if (rc != 0) return rc;
+  const DtpShard& sh = r->shards[bi];
+  hipStream_t cs = (hipStream_t)dtp_rccl_comm_stream(r->transport);
+  const float* h = r->hyper;
+  if (r->opt_kind == 1)
+    rc = r->sgd(sh.master, sh.grad, b.dtype_kind == 1, sh.s1, sh.lp, sh.n, h[0], h[1], h[2], h[3], 1.0f, r->iargs[0],
+                r->iargs[1], cs);
+  else
+    rc = r->adamw(sh.master, sh.grad, b.dtype_kind == 1, sh.s1, sh.s2, sh.lp, sh.n, h[0], h[1], h[2], h[3], h[4], 1.0f,
+                  r->iargs[0], cs);
+  if (rc != 0) return rc < 0 ? rc : -rc;
+  return dtp_rccl_all_gather_async(r->transport, sh.wbase, sh.wcount, r->wkind, cs, 1);
+}
 
 void* dtp_reducer_create(void* transport, int n_buckets, void* const* ptrs, const size_t* counts,
                          const int* dtype_kinds, int n_params, const int* pb_offsets, const int* pb_indices) {
@@ -237,7 +330,7 @@ int dtp_reducer_mark_ready(void* h, int param, hipStream_t producer_stream) {
     DtpBucket& b = r->buckets[bi];
     b.pending -= 1;
     if (b.pending == 0 && r->require_sync && !b.launched) {
-      const int rc = dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream);
+      const int rc = launch_bucket(r, bi, producer_stream);
       if (rc != 0) return rc < 0 ? rc : -rc;
       b.launched = true;
       r->launched += 1;
@@ -254,9 +347,10 @@ int dtp_reducer_finalize(void* h, hipStream_t stream) {
   if (!r) return -2;
   int n = 0;
   if (r->require_sync) {
-    for (auto& b : r->buckets) {
+    for (int bi = 0; bi < (int)r->buckets.size(); ++bi) {
+      DtpBucket& b = r->buckets[bi];
       if (b.launched) continue;
-      const int rc = dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, stream);
+      const int rc = launch_bucket(r, bi, stream);
       if (rc != 0) return rc < 0 ? rc : -rc;
       b.launched = true;
       r->launched += 1;
@@ -265,10 +359,45 @@ int dtp_reducer_finalize(void* h, hipStream_t stream) {
     const int rc = dtp_rccl_wait(r->transport, stream);
     if (rc != 0) return rc < 0 ? rc : -rc;
     r->passes += 1;
+    r->pass_armed = false;
   }
   for (auto& b : r->buckets) { b.pending = b.expected; b.launched = false; }
   std::fill(r->ready.begin(), r->ready.end(), 0);
   return n;
+}
+
+// Switch the scheduler to sharded mode.  Arrays have one entry per bucket; the slice pointers
+// address THIS rank's 1/world of the bucket.  opt_kind 1 = SGD (s2 unused), 2 = AdamW.
+int dtp_reducer_set_shard(void* h, int opt_kind, void* sgd_fn, void* adamw_fn, int n_buckets, void* const* master,
+                          void* const* grad, void* const* s1, void* const* s2, void* const* lp,
+                          const size_t* slice_counts, void* const* wbase, int wkind, int world) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r || n_buckets != (int)r->buckets.size() || world < 1) return -2;
+  if ((opt_kind == 1 && !sgd_fn) || (opt_kind == 2 && !adamw_fn) || opt_kind < 1 || opt_kind > 2) return -3;
+  r->shards.resize(n_buckets);
+  for (int b = 0; b < n_buckets; ++b) {
+    if (!master[b] || !grad[b] || !lp[b] || !wbase[b] || slice_counts[b] == 0 || (slice_counts[b] & 3)) return -4;
+    if (slice_counts[b] * (size_t)world != r->buckets[b].count) return -5;
+    r->shards[b] = DtpShard{(float*)master[b], grad[b], (float*)s1[b], (float*)(s2 ? s2[b] : nullptr), lp[b],
+                            slice_counts[b], wbase[b], slice_counts[b] * (size_t)world};
+  }
+  r->sgd = (dtp_sgd_fn)sgd_fn;
+  r->adamw = (dtp_adamw_fn)adamw_fn;
+  r->wkind = wkind;
+  r->opt_kind = opt_kind;
+  return 0;
+}
+
+// Per backward pass, before the first bucket can become ready: the optimizer's scalar arguments.
+// SGD: hyper = {lr, momentum, dampening, weight_decay}, iargs = {nesterov, first_step}.
+// AdamW: hyper = {lr, beta1, beta2, eps, weight_decay}, iargs = {step}.
+int dtp_reducer_begin_pass(void* h, const float* hyper, int n_hyper, const int* iargs, int n_iargs) {
+  auto* r = static_cast<DtpReducer*>(h);
+  if (!r || n_hyper > 8 || n_iargs > 4) return -2;
+  for (int i = 0; i < n_hyper; ++i) r->hyper[i] = hyper[i];
+  for (int i = 0; i < n_iargs; ++i) r->iargs[i] = iargs[i];
+  r->pass_armed = true;
+  return 0;
 }
 
 int dtp_reducer_set_sync(void* h, int on) {

@@ -8,6 +8,8 @@ stream (``record_stream`` keeps the allocator honest).  On CPU it is a transpare
 """
 import torch
 
+from ..utils.profiler import trace_range
+
 
 class DevicePrefetcher(object):
     def __init__(self, loader, device, depth=2):
@@ -23,7 +25,7 @@ class DevicePrefetcher(object):
     def _to_device(self, batch):
         if not self.cuda:
             return batch, None
-        with torch.cuda.stream(self.stream):
+        with trace_range("h2d"), torch.cuda.stream(self.stream):
             out = []
             for e in batch:
                 if torch.is_tensor(e):

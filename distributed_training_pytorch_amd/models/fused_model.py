@@ -76,10 +76,24 @@ class FusedModel(nn.Module):
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
-        if self._finalized:
+        if self._finalized and not self._still_in_arena():
             self._attach_arena()     # parameters were re-created/moved: re-home them in a fresh arena
             self._after_rehome()
         return out
+
+    def _still_in_arena(self):
+        """True when ``_apply`` was a no-op for the parameters (``.to()`` of the device/dtype they
+        already have): optimizers, reducers and captured graphs hold views of THIS arena, so it
+        must not be rebuilt behind their back."""
+        a = self.param_arena
+        if a is None:
+            return False
+        base = a.flat_master.untyped_storage().data_ptr()
+        for p in a.params:
+            if (p.device != a.device or p.dtype != torch.float32
+                    or p.data.untyped_storage().data_ptr() != base):
+                return False
+        return len(a.params) == sum(1 for q in self.parameters() if q.requires_grad)
 
     def _after_rehome(self):
         """Hook for subclasses that keep device-side constants (e.g. input normalisation)."""

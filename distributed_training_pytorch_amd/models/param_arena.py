@@ -39,11 +39,14 @@ class ParamArena(object):
             self.offsets.append(off)
             off += _round_up(p.numel())
         self.total = off
+        # zero tail padding: lets the sharded reducer round its last bucket up to a multiple of
+        # world * 64 elements (any world size <= 64) without leaving the arena
+        self.capacity = (off + 4095) // 4096 * 4096
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.grad_dtype = grad_dtype
-        self.flat_master = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-        self.flat_grad = torch.zeros(self.total, dtype=grad_dtype, device=self.device)
-        self.flat_lp = (torch.zeros(self.total, dtype=lp_dtype, device=self.device)
+        self.flat_master = torch.zeros(self.capacity, dtype=torch.float32, device=self.device)
+        self.flat_grad = torch.zeros(self.capacity, dtype=grad_dtype, device=self.device)
+        self.flat_lp = (torch.zeros(self.capacity, dtype=lp_dtype, device=self.device)
                         if self.device.type == "cuda" else None)
         self.fresh = [True] * len(self.params)
         self.kernel_written = set()   # id(p) of params whose grads are written by fused kernels

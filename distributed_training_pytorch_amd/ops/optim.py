@@ -35,12 +35,42 @@ class _FusedBase(torch.optim.Optimizer):
 
     def __init__(self, model, defaults):
         self.arena = _arena_from(model)
+        import weakref
+        owner = model if getattr(model, "param_arena", None) is not None else getattr(model, "module", None)
+        self._model_ref = weakref.ref(owner) if owner is not None and hasattr(owner, "param_arena") else None
         super().__init__(self.arena.params, defaults)
         if len(self.param_groups) != 1:
             raise ValueError("fused optimizers support a single parameter group")
         self._flat_state = {k: torch.zeros_like(self.arena.flat_master) for k in self._state_keys}
         self._steps = 0
+        # sharded mode (parallel/reducer.py, ``shard_optimizer``): the gradient reducer runs
+        # ``update_range`` on this rank's slice of every bucket between the bucket's reduce-scatter
+        # and its all-gather; ``step()`` then only closes the pass
+        self._sharded_by = None
+        self._external_pass_done = False
         self._bind_state_views()
+
+    def _check_arena(self):
+        """The model may have been re-homed (``.to()`` builds a fresh arena): stepping the orphaned
+        buffers would silently train nothing."""
+        live = getattr(self, "_model_ref", None)
+        live = live() if live is not None else None
+        if live is not None and getattr(live, "param_arena", None) is not self.arena:
+            raise RuntimeError("the model's ParamArena was rebuilt after this optimizer was created "
+                               "(model.to()/float() after build_optimizer): create the optimizer after "
+                               "the model is on its final device")
+
+    def flat_state_tensors(self):
+        """Flat optimizer-state buffers (same layout as the arena), for sharded-state consolidation."""
+        return list(self._flat_state.values())
+
+    def begin_external_pass(self):
+        """Called by the sharded reducer before it starts updating slices in a backward pass:
+        returns the per-pass constants the slice updates need (e.g. the step number)."""
+        raise NotImplementedError
+
+    def step_closed_by_reducer(self):
+        self._external_pass_done = True
 
     def _bind_state_views(self):
         a = self.arena
@@ -98,29 +128,52 @@ class FusedSGD(_FusedBase):
                                      weight_decay=weight_decay, nesterov=nesterov, maximize=False,
                                      foreach=None, differentiable=False, fused=None))
 
+    def begin_external_pass(self):
+        return dict(first=self._steps == 0)
+
+    @torch.no_grad()
+    def update_range(self, lo, hi, grad_scale=1.0, first=None):
+        """SGD-momentum update of arena elements [lo, hi) only (whole arena: ``step``)."""
+        a, g = self.arena, self.param_groups[0]
+        first = (self._steps == 0) if first is None else first
+        mom = self._flat_state["momentum_buffer"]
+        if a.flat_master.is_cuda:
+            K.sgd_flat(a.flat_master[lo:hi], a.flat_grad[lo:hi], mom[lo:hi], a.flat_lp[lo:hi], g["lr"], g["momentum"],
+                       g["dampening"], g["weight_decay"], grad_scale, g["nesterov"], first)
+            return
+        m, p = mom[lo:hi], a.flat_master[lo:hi]
+        d = a.flat_grad[lo:hi].float() * grad_scale
+        if g["weight_decay"] != 0:
+            d = d.add(p, alpha=g["weight_decay"])
+        if g["momentum"] != 0:
+            if first:
+                m.copy_(d)
+            else:
+                m.mul_(g["momentum"]).add_(d, alpha=1 - g["dampening"])
+            d = d.add(m, alpha=g["momentum"]) if g["nesterov"] else m
+        p.add_(d, alpha=-g["lr"])
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
-        a, g = self.arena, self.param_groups[0]
-        first = self._steps == 0
-        mom = self._flat_state["momentum_buffer"]
+        a = self.arena
+        self._check_arena()
+        if self._sharded_by is not None:
+            if not self._external_pass_done:
+                raise RuntimeError("sharded optimizer: step() needs a synchronised backward pass first "
+                                   "(the reducer updates the slices; do not call step() inside no_sync())")
+            self._external_pass_done = False
+            if a.flat_master.is_cuda:
+                a.lp_written_by_optimizer()
+            self._steps += 1
+            return loss
         if a.flat_master.is_cuda:
             a.collect_autograd_grads()
-            K.sgd_flat(a.flat_master, a.flat_grad, mom, a.flat_lp, g["lr"], g["momentum"], g["dampening"],
-                       g["weight_decay"], grad_scale, g["nesterov"], first)
-            a.lp_written_by_optimizer()
         else:
             a.gather_autograd_grads()
-            d = a.flat_grad.float() * grad_scale
-            if g["weight_decay"] != 0:
-                d = d.add(a.flat_master, alpha=g["weight_decay"])
-            if g["momentum"] != 0:
-                if first:
-                    mom.copy_(d)
-                else:
-                    mom.mul_(g["momentum"]).add_(d, alpha=1 - g["dampening"])
-                d = d.add(mom, alpha=g["momentum"]) if g["nesterov"] else mom
-            a.flat_master.add_(d, alpha=-g["lr"])
+        self.update_range(0, a.flat_master.numel(), grad_scale)
+        if a.flat_master.is_cuda:
+            a.lp_written_by_optimizer()
         self._steps += 1
         return loss
 
@@ -131,26 +184,48 @@ class FusedAdamW(_FusedBase):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(model, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
+    def begin_external_pass(self):
+        return dict(step=self._steps + 1)
+
+    @torch.no_grad()
+    def update_range(self, lo, hi, grad_scale=1.0, step=None):
+        a, g = self.arena, self.param_groups[0]
+        b1, b2 = g["betas"]
+        step = (self._steps + 1) if step is None else step
+        m, v = self._flat_state["exp_avg"][lo:hi], self._flat_state["exp_avg_sq"][lo:hi]
+        if a.flat_master.is_cuda:
+            K.adamw_flat(a.flat_master[lo:hi], a.flat_grad[lo:hi], m, v, a.flat_lp[lo:hi], g["lr"], b1, b2, g["eps"],
+                         g["weight_decay"], grad_scale, step)
+            return
+        p = a.flat_master[lo:hi]
+        d = a.flat_grad[lo:hi].float() * grad_scale
+        p.mul_(1 - g["lr"] * g["weight_decay"])
+        m.mul_(b1).add_(d, alpha=1 - b1)
+        v.mul_(b2).addcmul_(d, d, value=1 - b2)
+        bc1 = 1 - b1 ** step
+        bc2 = 1 - b2 ** step
+        denom = (v.sqrt() / (bc2 ** 0.5)).add_(g["eps"])
+        p.addcdiv_(m, denom, value=-g["lr"] / bc1)
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
-        a, g = self.arena, self.param_groups[0]
-        b1, b2 = g["betas"]
-        m, v = self._flat_state["exp_avg"], self._flat_state["exp_avg_sq"]
-        self._steps += 1
+        a = self.arena
+        self._check_arena()
+        if self._sharded_by is not None:
+            if not self._external_pass_done:
+                raise RuntimeError("sharded optimizer: step() needs a synchronised backward pass first")
+            self._external_pass_done = False
+            if a.flat_master.is_cuda:
+                a.lp_written_by_optimizer()
+            self._steps += 1
+            return loss
         if a.flat_master.is_cuda:
             a.collect_autograd_grads()
-            K.adamw_flat(a.flat_master, a.flat_grad, m, v, a.flat_lp, g["lr"], b1, b2, g["eps"],
-                         g["weight_decay"], grad_scale, self._steps)
-            a.lp_written_by_optimizer()
         else:
             a.gather_autograd_grads()
-            d = a.flat_grad.float() * grad_scale
-            a.flat_master.mul_(1 - g["lr"] * g["weight_decay"])
-            m.mul_(b1).add_(d, alpha=1 - b1)
-            v.mul_(b2).addcmul_(d, d, value=1 - b2)
-            bc1 = 1 - b1 ** self._steps
-            bc2 = 1 - b2 ** self._steps
-            denom = (v.sqrt() / (bc2 ** 0.5)).add_(g["eps"])
-            a.flat_master.addcdiv_(m, denom, value=-g["lr"] / bc1)
+        self.update_range(0, a.flat_master.numel(), grad_scale)
+        if a.flat_master.is_cuda:
+            a.lp_written_by_optimizer()
+        self._steps += 1
         return loss

@@ -74,3 +74,14 @@ def broadcast_object(obj, src=0):
     box = [obj]
     dist.broadcast_object_list(box, src=src, device=comm_device())
     return box[0]
+
+
+def all_gather_object(obj):
+    """List of every rank's ``obj`` (``[obj]`` without a process group)."""
+    if not (is_dist() and dist.get_world_size() > 1):
+        return [obj]
+    out = [None] * dist.get_world_size()
+    if dist.get_backend() == "nccl":
+        torch.cuda.set_device(torch.cuda.current_device())
+    dist.all_gather_object(out, obj)
+    return out

@@ -7,9 +7,10 @@ Parity target: reference ``trainer/trainer.py:52`` (``DDP(model, device_ids=[loc
 
 What happens at construction: rank 0's parameters and buffers are broadcast
 as a few flat messages; then a :class:`BucketedReducer` takes over gradient synchronisation.
-Buffers (BatchNorm running stats of VGG16-BN) are re-broadcast from rank 0 at the start of a
-*training* forward only — never in eval — which removes the rank-0-only-validation deadlock of
-SURVEY.md §2.6 quirk #9.
+Buffers (BatchNorm running stats of VGG16-BN) follow rank 0 like under DDP, but lazily: they are
+broadcast when the wrapper switches to eval mode and before a snapshot (``sync_buffers``), not at
+every training forward — and never from inside an eval forward, which removes the
+rank-0-only-validation deadlock of SURVEY.md §2.6 quirk #9.
 """
 import torch
 import torch.nn as nn
@@ -20,19 +21,25 @@ from .reducer import BucketedReducer, TorchPGTransport
 
 class DataParallel(nn.Module):
     def __init__(self, module, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
-                 reduce_dtype=None, broadcast_buffers=True, transport=None, sync_init=True):
+                 reduce_dtype=None, broadcast_buffers=True, transport=None, sync_init=True,
+                 shard_optimizer=None, bucket_align_elems=None):
         super().__init__()
         self.module = module
         self.broadcast_buffers = broadcast_buffers
         arena = getattr(module, "param_arena", None)
+        self._arena = arena
+        self._buffers_dirty = False
         params = [p for p in module.parameters() if p.requires_grad]
         if transport is None:
             transport = self._pick_transport(params[0].device if params else torch.device("cpu"))
         kw = dict(bucket_cap_mb=bucket_cap_mb, first_bucket_mb=first_bucket_mb,
                   split_large_mb=split_large_mb, reduce_dtype=reduce_dtype, transport=transport)
+        if shard_optimizer is not None and not (arena is not None and arena.is_flat):
+            raise ValueError("shard_optimizer needs a model with a flat ParamArena")
         if arena is not None and arena.is_flat:
             self.reducer = BucketedReducer(arena.params, flat_grad=arena.flat_grad,
-                                           flat_offsets=arena.offsets, **kw)
+                                           flat_offsets=arena.offsets, shard_optimizer=shard_optimizer,
+                                           bucket_align_elems=bucket_align_elems, **kw)
             arena.reducer = self.reducer
             self.reducer.pre_ready = arena.sync_autograd_grad
         else:
@@ -43,53 +50,24 @@ class DataParallel(nn.Module):
     @staticmethod
     def _pick_transport(device):
         """Native RCCL transport (own communicator + comm stream, C++) on GPUs, the
-        ``torch.distributed`` process group otherwise.  ``DTP_TRANSPORT=torch|native`` forces one (default: native when it comes up everywhere).
-        All ranks must end up with the same kind: the outcome of the native set-up (communicator
-        creation plus one self-checked all-reduce) is agreed on through the process group before
-        anyone uses it."""
+        ``torch.distributed`` process group otherwise.  ``DTP_TRANSPORT=torch|native`` forces one
+        (default ``auto``: native when it comes up on every rank).  All ranks end up with the same
+        kind: ``rccl_native.bring_up`` runs on the calling thread and agrees on the outcome through
+        the process group before anyone uses the transport."""
         import os
         want = os.environ.get("DTP_TRANSPORT", "auto").lower()
+        info = dict(requested=want, kind="torch", fell_back=os.environ.get("DTP_NATIVE_FELL_BACK") == "1",
+                    reason="relaunched by the self-launcher after a native bring-up timeout"
+                    if os.environ.get("DTP_NATIVE_FELL_BACK") == "1" else None)
         if device.type != "cuda" or not comm.is_dist() or comm.world_size() == 1 or want == "torch":
-            return TorchPGTransport()
-        # The set-up runs in a watchdog thread: a communicator that never comes up (a rank stuck in
-        # ncclCommInitRank or in the probe collective) must degrade to the process-group transport
-        # after DTP_NATIVE_INIT_TIMEOUT_S seconds instead of hanging the job.
-        import threading
-        box = dict(native=None, ok=0.0)
-
-        def _bring_up():
-            try:
-                torch.cuda.set_device(device)                 # current device is per thread
-                from .rccl_native import NativeRcclTransport
-                box["native"] = NativeRcclTransport(device=device.index if device.index is not None
-                                                    else torch.cuda.current_device())
-                probe = torch.full((256,), float(comm.rank() + 1), device=device)
-                box["native"].wait(box["native"].launch(probe), probe)
-                torch.cuda.current_stream().synchronize()
-                expect = (comm.world_size() + 1) / 2.0        # mean of 1..world
-                box["ok"] = 1.0 if bool(((probe - expect).abs() < 1e-5).all()) else 0.0
-            except Exception:
-                box["ok"] = 0.0
-
-        th = threading.Thread(target=_bring_up, name="dtp-native-rccl-init", daemon=True)
-        th.start()
-        th.join(float(os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", "120")))
-        timed_out = th.is_alive()
-        native, ok = (None, 0.0) if timed_out else (box["native"], box["ok"])
-        agreed = comm.all_reduce_scalars([ok], op="min")[0]
-        if agreed >= 1.0:
-            return native
-        if native is not None:
-            native.close()
-        if comm.rank() == 0:
-            import warnings
-            warnings.warn("native RCCL transport unavailable (%s on at least one rank); gradients go through the "
-                          "torch.distributed process group" % ("bring-up timed out" if timed_out else
-                                                               "bring-up or self-check failed" if ok < 1.0 else
-                                                               "another rank failed"))
-        if want == "native":
-            raise RuntimeError("DTP_TRANSPORT=native but the RCCL transport did not come up on every rank")
-        return TorchPGTransport()
+            t = TorchPGTransport()
+            t.info = info
+            return t
+        from .rccl_native import bring_up
+        native, info = bring_up(device, want)
+        t = native if native is not None else TorchPGTransport()
+        t.info = info
+        return t
 
     def sync_module_states(self):
         arena = getattr(self.module, "param_arena", None)
@@ -102,13 +80,38 @@ class DataParallel(nn.Module):
         if bufs:
             self.reducer.broadcast_parameters(bufs)
 
-    def forward(self, *args, **kwargs):
-        if (self.broadcast_buffers and self.training and self.reducer.world > 1
-                and self.reducer.require_sync):
+    def consolidate(self):
+        """Collective (all ranks): complete the fp32 master weights and the optimizer state before
+        ``state_dict()`` when the optimizer is sharded; a no-op otherwise."""
+        self.reducer.consolidate()
+        if self.broadcast_buffers:
+            self.sync_buffers()
+
+    def sync_buffers(self):
+        """Collective: rank 0's floating-point buffers (BatchNorm running statistics) to every rank.
+        Stock DDP re-broadcasts them at the start of EVERY training forward (reference
+        ``trainer/trainer.py:52``); nothing reads the other ranks' copies during
+        training, so here they are synchronised lazily — when the wrapper switches to eval mode and
+        before a snapshot — with the same values at every point where they are observable."""
+        if self.reducer.world > 1 and self._buffers_dirty:
             bufs = [b for b in self.module.buffers() if b.numel() > 0 and b.is_floating_point()
                     and getattr(b, "_dtp_sync", True)]
             if bufs:
                 self.reducer.broadcast_parameters(bufs)
+        self._buffers_dirty = False
+
+    def train(self, mode=True):
+        if not mode and self.broadcast_buffers and getattr(self, "reducer", None) is not None:
+            self.sync_buffers()
+        return super().train(mode)
+
+    def forward(self, *args, **kwargs):
+        if getattr(self.module, "param_arena", None) is not self._arena:
+            raise RuntimeError("the model's ParamArena was rebuilt after DataParallel wrapped it (model.to() / "
+                               ".float() on the wrapped module): the reducer's buckets point at the old "
+                               "gradient arena — wrap the model after it is on its final device")
+        if self.training:
+            self._buffers_dirty = True       # running statistics move: re-sync before anyone reads them
         return self.module(*args, **kwargs)
 
     def no_sync(self):

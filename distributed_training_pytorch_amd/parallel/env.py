@@ -40,6 +40,24 @@ def gpu_available():
     return torch.cuda.is_available()
 
 
+def apply_rccl_env_defaults(nnodes=None):
+    """Export the RCCL / HIP tunables this framework wants (``launch.rccl_env_defaults``) unless the
+    operator already set them.  ``run.sh`` and the self-launcher export the same values before the
+    workers start; calling it here as well covers any other launcher (torchrun by hand, SLURM).
+    Must run before the first RCCL communicator is created — ``ddp_setup`` does."""
+    from ..launch import rccl_env_defaults
+    if nnodes is None:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)) or world)
+        nnodes = max(1, world // max(local, 1))
+    applied = {}
+    for k, v in rccl_env_defaults(nnodes).items():
+        if k not in os.environ:
+            os.environ[k] = v
+            applied[k] = v
+    return applied
+
+
 def default_device(local_rank=None):
     """cuda:<local_rank> when a GPU is visible and the process group (if any) is not gloo."""
     if local_rank is None:
@@ -58,6 +76,7 @@ def ddp_setup(backend="nccl", timeout_s=None):
     group entirely; every collective helper in :mod:`comm` degrades to a no-op in that case.
     """
     env = DistEnv.from_env()
+    apply_rccl_env_defaults()
     if backend == "nccl" and not gpu_available():
         raise RuntimeError(
             "backend='nccl' (RCCL) needs a visible GPU; use backend='gloo' for the CPU path")

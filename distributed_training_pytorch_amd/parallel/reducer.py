@@ -18,6 +18,12 @@ This module re-implements that contract, transport-agnostic:
   * transports: ``torch.distributed`` process group (gloo on CPU for tests, RCCL through
     ``backend="nccl"``), or the native RCCL transport of ``parallel/rccl_native.py`` (own
     communicator + dedicated HIP stream, C++).
+  * sharded mode (``shard_optimizer=``): per bucket reduce-scatter ->
+    the fused optimizer updates this rank's 1/world slice -> all-gather of the updated working
+    weights.  Same bytes on the links as the all-reduce (RS + AG *is* an all-reduce), but the
+    optimizer pass shrinks to 1/world per GPU and runs per bucket on the communication stream while
+    backward is still producing the later buckets; bucket boundaries are snapped to multiples of
+    ``world * 64`` elements so every bucket splits evenly.
   * ``no_sync()`` gives gradient accumulation (skip all-reduce on non-boundary micro-steps,
     SURVEY.md §5.7); the averaging divide is folded into the collective (``AVG`` on RCCL) or
     one fused scale per bucket.
@@ -69,7 +75,7 @@ def plan_buckets(numels, elem_bytes, first_cap_bytes, cap_bytes, split_large_byt
 
 class _Bucket(object):
     __slots__ = ("index", "entries", "flat", "pending", "expected", "work", "launched",
-                 "comm_buf", "param_ids")
+                 "comm_buf", "param_ids", "lo", "hi")
 
     def __init__(self, index, entries, flat):
         self.index = index
@@ -81,6 +87,7 @@ class _Bucket(object):
         self.work = None
         self.launched = False
         self.comm_buf = None
+        self.lo = self.hi = None    # arena element range (arena mode)
 
 
 _GLOO_STAGE_HOST = os.environ.get("DTP_GLOO_STAGE_HOST", "1") == "1"
@@ -115,9 +122,46 @@ class TorchPGTransport(object):
             work.wait()
             flat.copy_(host.mul_(1.0 / self.world), non_blocking=False)
             return
+        if kind == "rs":
+            work, out, dst = work
+            work.wait()
+            dst.copy_(out)
+            return
+        if kind == "ag_host":
+            work, host = work
+            work.wait()
+            flat.copy_(host)
+            return
         work.wait()
         if kind == "sum":
             flat.mul_(1.0 / self.world)
+
+    # ---- sharded mode: reduce-scatter / all-gather over a bucket that splits evenly over ranks
+    def reduce_scatter(self, flat):
+        """Average ``flat`` over the ranks; after ``wait`` rank r's slice ``flat[r*S:(r+1)*S]``
+        (S = numel / world) holds the result (the other slices are unspecified)."""
+        if self.world == 1:
+            return None
+        rank = dist.get_rank(self.pg)
+        S = flat.numel() // self.world
+        if self.backend == "nccl":
+            out = torch.empty(S, dtype=flat.dtype, device=flat.device)
+            w = dist.reduce_scatter_tensor(out, flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            return ("rs", (w, out, flat[rank * S:(rank + 1) * S]))
+        return self.launch(flat)          # gloo has no reduce-scatter: all-reduce, the slice is what is used
+
+    def all_gather(self, flat):
+        """Every rank contributes its slice of ``flat``; after ``wait`` all of ``flat`` is current."""
+        if self.world == 1:
+            return None
+        rank = dist.get_rank(self.pg)
+        S = flat.numel() // self.world
+        if flat.is_cuda and self.backend != "nccl" and _GLOO_STAGE_HOST:
+            host = flat.to("cpu")
+            w = dist.all_gather_into_tensor(host, host[rank * S:(rank + 1) * S].clone(), group=self.pg, async_op=True)
+            return ("ag_host", (w, host))
+        w = dist.all_gather_into_tensor(flat, flat[rank * S:(rank + 1) * S].clone(), group=self.pg, async_op=True)
+        return ("ag", w)
 
     def broadcast(self, flat, src=0):
         if self.world > 1:
@@ -132,7 +176,7 @@ class TorchPGTransport(object):
 class BucketedReducer(object):
     def __init__(self, params, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
                  reduce_dtype=None, transport=None, flat_grad=None, flat_offsets=None,
-                 grad_dtype=None):
+                 grad_dtype=None, shard_optimizer=None, bucket_align_elems=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("BucketedReducer needs at least one trainable parameter")
@@ -173,15 +217,45 @@ class BucketedReducer(object):
 
         self.buckets = []
         self._param_buckets = {}
+        self.sharded = False
+        self.opt = None
+        if shard_optimizer is not None:
+            if flat_grad is None or getattr(shard_optimizer, "arena", None) is None \
+                    or shard_optimizer.arena.flat_grad is not flat_grad:
+                raise ValueError("shard_optimizer needs a fused flat-arena optimizer of the same model")
+            if reduce_dtype is not None and reduce_dtype != flat_grad.dtype:
+                raise ValueError("sharded mode reduces the gradient arena in place (no reduce_dtype)")
+            self.sharded = self.world > 1
+            self.opt = shard_optimizer
         if flat_grad is not None:
-            # arena mode: params' grads already are views of flat_grad at flat_offsets[i]
+            # arena mode: params' grads already are views of flat_grad at flat_offsets[i]; a bucket is
+            # a contiguous element range [lo, hi) of the arena
             assert flat_offsets is not None and len(flat_offsets) == len(self.params)
-            for bi, ranges in enumerate(plan):
-                lo = min(flat_offsets[i] + s for i, s, e in ranges)
-                hi = max(flat_offsets[i] + e for i, s, e in ranges)
-                # [lo, hi) may include the arena's alignment padding (always zero): harmless
-                entries = [(self.params[i], s, e, flat_offsets[i] + s - lo) for i, s, e in ranges]
-                self._add_bucket(_Bucket(bi, entries, flat_grad[lo:hi]))
+            cuts = sorted(set(min(flat_offsets[i] + s for i, s, e in ranges) for ranges in plan))
+            end = max(flat_offsets[i] + numels[i] for i in range(len(numels)))
+            if self.sharded or bucket_align_elems:
+                # every bucket must split evenly over the ranks into 64-element-aligned slices:
+                # snap the interior cuts down, extend the end into the arena's zero tail padding
+                # (bucket_align_elems: the same plan without sharding, for A/B and parity tests)
+                q = self.world * 64 if self.sharded else int(bucket_align_elems)
+                cuts = sorted(set((c // q) * q for c in cuts))
+                end = (end + q - 1) // q * q
+                if end > flat_grad.numel():
+                    raise ValueError("gradient arena has no tail padding for %d-way sharding" % self.world)
+            cuts = [c for c in cuts if c < end] + [end]
+            ranges_desc = [(cuts[k], cuts[k + 1]) for k in range(len(cuts) - 1)][::-1]   # reverse registration order
+            for bi, (lo, hi) in enumerate(ranges_desc):
+                entries = []
+                for i, p in enumerate(self.params):
+                    o, n = flat_offsets[i], numels[i]
+                    a, b = max(lo, o), min(hi, o + n)
+                    if a < b:
+                        entries.append((p, a - o, b - o, a - lo))
+                if not entries:
+                    continue
+                bk = _Bucket(len(self.buckets), entries, flat_grad[lo:hi])
+                bk.lo, bk.hi = lo, hi
+                self._add_bucket(bk)
             self._owns_grads = False
         else:
             for bi, ranges in enumerate(plan):
@@ -194,13 +268,18 @@ class BucketedReducer(object):
                 self._add_bucket(_Bucket(bi, entries, flat))
             self._owns_grads = True
             self._point_grads()
+        if self.sharded:
+            self.opt._sharded_by = self
+            self._rank = comm.rank()
+            self._pass = None           # per-pass constants from the optimizer (first step flag / step number)
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         if (flat_grad is not None and hasattr(self.transport, "make_scheduler")
                 and (reduce_dtype is None or reduce_dtype == flat_grad.dtype)):
             self._param_index = {id(p): i for i, p in enumerate(self.params)}
             lists = [[b.index for b in self._param_buckets[id(p)]] for p in self.params]
-            self._core = self.transport.make_scheduler([b.flat for b in self.buckets], lists)
+            self._core = self.transport.make_scheduler([b.flat for b in self.buckets], lists,
+                                                       shard=self._native_shard_spec() if self.sharded else None)
             self._total_bytes = sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
     @property
@@ -238,7 +317,48 @@ class BucketedReducer(object):
     def bucket_summary(self):
         return [dict(index=b.index, numel=int(b.flat.numel()),
                      mbytes=b.flat.numel() * b.flat.element_size() / 2 ** 20,
-                     n_params=b.expected) for b in self.buckets]
+                     n_params=b.expected, range=(b.lo, b.hi)) for b in self.buckets]
+
+    # ------------------------------------------------------------------ sharded mode helpers
+    def my_slice(self, b):
+        """Arena element range of bucket ``b`` this rank owns (updates and contributes)."""
+        S = (b.hi - b.lo) // self.world
+        return b.lo + self._rank * S, b.lo + (self._rank + 1) * S
+
+    def _weights_flat(self):
+        """What the all-gather distributes: the bf16 working copy on GPUs (half the bytes; the fp32
+        master of non-owned slices goes stale until :meth:`consolidate`), the fp32 master on CPU."""
+        a = self.opt.arena
+        return a.flat_lp if a.flat_lp is not None else a.flat_master
+
+    def _native_shard_spec(self):
+        a = self.opt.arena
+        return dict(optimizer=self.opt, arena=a, weights=self._weights_flat(),
+                    ranges=[(b.lo, b.hi) for b in self.buckets], rank=self._rank, world=self.world)
+
+    def _begin_pass(self):
+        if self._pass is None:
+            self._pass = self.opt.begin_external_pass()
+            if self._core is not None:
+                self._core.begin_pass(self.opt, self._pass)
+        return self._pass
+
+    def consolidate(self):
+        """Collective: make the fp32 master weights and the optimizer state complete on every rank
+        (all-gather of the owned slices).  Call on ALL ranks before ``state_dict()`` / a snapshot."""
+        if not self.sharded:
+            return
+        a = self.opt.arena
+        tensors = list(self.opt.flat_state_tensors())
+        if a.flat_lp is not None:
+            tensors.append(a.flat_master)       # on CPU the hot path already gathers the master
+        tr = self.transport
+        for t in tensors:
+            for b in self.buckets:
+                seg = t[b.lo:b.hi]
+                tr.wait(tr.all_gather(seg), seg)
+        if a.flat_master.is_cuda:
+            torch.cuda.current_stream().synchronize()
 
     # ------------------------------------------------------------------ backward-time path
     def _on_grad_ready(self, p):
@@ -263,6 +383,8 @@ class BucketedReducer(object):
         if self.pre_ready is not None:
             self.pre_ready(p)
         if self._core is not None:       # counting + launch in C++ (one call)
+            if self.sharded and self.require_sync:
+                self._begin_pass()       # the C++ side needs this pass's optimizer constants first
             self.stats["launched"] += self._core.mark_ready(self._param_index[id(p)])
             return
         for b in self._param_buckets[id(p)]:
@@ -292,6 +414,12 @@ class BucketedReducer(object):
             return
         b.launched = True
         buf = b.flat
+        if self.sharded:
+            self._begin_pass()
+            b.work = self.transport.reduce_scatter(buf)
+            self.stats["launched"] += 1
+            self.stats["bytes"] += buf.numel() * buf.element_size()
+            return
         if self.reduce_dtype is not None and self.reduce_dtype != buf.dtype:
             b.comm_buf = buf.to(self.reduce_dtype)
             buf = b.comm_buf
@@ -306,6 +434,8 @@ class BucketedReducer(object):
             if self.require_sync and self.measure_exposed and self.world > 1:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
+            if self.sharded and self.require_sync:
+                self._begin_pass()
             self.stats["launched"] += self._core.finalize()
             if self.require_sync:
                 if ev0 is not None:
@@ -313,6 +443,9 @@ class BucketedReducer(object):
                     self._exposed_pairs.append((ev0, ev1))
                 self.stats["finalized"] += 1
                 self.stats["bytes"] += self._total_bytes
+                if self.sharded:
+                    self.opt.step_closed_by_reducer()
+                    self._pass = None
             self._ready_ids.clear()
             return
         if self.require_sync:
@@ -323,7 +456,23 @@ class BucketedReducer(object):
             if self.measure_exposed and self.world > 1:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            for b in self.buckets:
+            if self.sharded:
+                # per bucket, in launch order: reduce-scatter done -> update the owned slice ->
+                # all-gather of the updated weights (queued async; joined below)
+                kw = self._begin_pass()
+                w = self._weights_flat()
+                gathers = []
+                for b in self.buckets:
+                    self.transport.wait(b.work, b.flat)
+                    lo, hi = self.my_slice(b)
+                    self.opt.update_range(lo, hi, **kw)
+                    seg = w[b.lo:b.hi]
+                    gathers.append((self.transport.all_gather(seg), seg))
+                for h, seg in gathers:
+                    self.transport.wait(h, seg)
+                self.opt.step_closed_by_reducer()
+                self._pass = None
+            for b in (() if self.sharded else self.buckets):
                 buf = b.comm_buf if b.comm_buf is not None else b.flat
                 self.transport.wait(b.work, buf)
                 if b.comm_buf is not None:

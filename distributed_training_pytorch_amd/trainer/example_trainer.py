@@ -21,6 +21,7 @@ from ..data.synthetic import SyntheticImageDataset
 from ..models.vgg16 import VGG16
 from ..ops.layers import SoftmaxCrossEntropy, top1_hits
 from ..ops.optim import FusedSGD
+from ..utils.profiler import trace_range
 from .trainer import Trainer
 
 
@@ -122,16 +123,21 @@ class ExampleTrainer(Trainer):
             return dict(ce_loss=self.graphed_step(img_batch, lb_batch))
         micro = getattr(self, "micro_step", 0)
         first = micro % self.grad_accum_steps == 0
-        sync = self.should_sync(micro)
+        sync = self.should_sync(micro)           # also True on the epoch's last step: short windows are flushed
+        window = self.accum_window(micro)        # micro-steps in this window (== grad_accum_steps except at the tail)
         if first:
             self.optimizer.zero_grad()
         ctx = contextlib.nullcontext() if sync else self.model.no_sync()
+        timer = self.step_timer
         with ctx, torch.set_grad_enabled(True):
-            out = self.model(img_batch)
-            loss = self.criterion(out, lb_batch)
-            (loss / self.grad_accum_steps if self.grad_accum_steps > 1 else loss).backward()
+            with trace_range("fwd"), timer.phase("fwd"):
+                out = self.model(img_batch)
+                loss = self.criterion(out, lb_batch)
+            with trace_range("bwd"), timer.phase("bwd"):
+                (loss / window if window > 1 else loss).backward()
         if sync:
-            self.optimizer.step()
+            with trace_range("optimizer"), timer.phase("optimizer"):
+                self.optimizer.step()
         return dict(ce_loss=loss.detach())
 
     def validate_step(self, batch):

@@ -35,7 +35,7 @@ from ..parallel import comm, env as penv
 from ..parallel.data_parallel import DataParallel
 from ..parallel.sampler import ShardedSampler
 from ..utils import checkpoint as ckpt
-from ..utils.meter import ThroughputMeter
+from ..utils.meter import StepTimer, ThroughputMeter
 
 try:
     from tqdm import tqdm as _tqdm
@@ -74,7 +74,9 @@ class Trainer(object):
                  metrics_file=None,
                  seed=0,
                  use_hip_graph=False,
-                 cache_dataset_on_device=False):
+                 cache_dataset_on_device=False,
+                 shard_optimizer=False,
+                 step_timing=None):
         # T1 logging shim (plain method, keyword-friendly; reference :26)
         self.logger = logger
         # T5 rank discovery (reference :48-50) — defaults make `python main.py` work
@@ -117,6 +119,12 @@ class Trainer(object):
         self.best_fitness = dict(epoch=None, value=None, metrics=None)
         self.metrics_file = metrics_file
         self.meter = ThroughputMeter()
+        # per-phase GPU timings (forward / backward / optimizer) from HIP events, resolved once per
+        # epoch; opt-in (DTP_STEP_TIMING=1) because every event costs a launch-sized host call
+        if step_timing is None:
+            step_timing = os.environ.get("DTP_STEP_TIMING", "0") == "1"
+        self.step_timer = StepTimer(enabled=bool(step_timing))
+        self.steps_this_epoch = None
         # capture the whole train step into one hipGraph (engine/graph.py); hooks opt in through
         # self.graphed_step — only single-process runs without gradient accumulation are captured
         # keep whole (small enough) datasets resident on the GPU and gather batches there
@@ -136,7 +144,10 @@ class Trainer(object):
             self._load_snapshot(snapshot_path)
 
         # gradient synchronisation (replaces DDP; broadcasts rank 0's state, X2)
-        self.model = DataParallel(self.model, bucket_cap_mb=bucket_cap_mb, reduce_dtype=reduce_dtype)
+        # shard_optimizer: reduce-scatter + per-bucket optimizer on 1/world of the arena + all-gather
+        # (parallel/reducer.py) instead of all-reduce + replicated optimizer
+        self.model = DataParallel(self.model, bucket_cap_mb=bucket_cap_mb, reduce_dtype=reduce_dtype,
+                                  shard_optimizer=self.optimizer if (shard_optimizer and self.world_size > 1) else None)
         if self.use_hip_graph and self.device.type == "cuda" and self.grad_accum_steps == 1:
             from ..engine.graph import GraphedTrainStep
             self.graphed_step = GraphedTrainStep(self.model, self.criterion, self.optimizer)
@@ -206,8 +217,21 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ helpers for hooks
     def should_sync(self, micro_step):
-        """True when this micro-step ends a gradient-accumulation window."""
-        return (micro_step + 1) % self.grad_accum_steps == 0
+        """True when this micro-step ends a gradient-accumulation window: every
+        ``grad_accum_steps`` micro-steps, and at the LAST step of the epoch — a trailing short
+        window is flushed (synchronised + stepped), never dropped."""
+        if (micro_step + 1) % self.grad_accum_steps == 0:
+            return True
+        return self.steps_this_epoch is not None and micro_step + 1 >= self.steps_this_epoch
+
+    def accum_window(self, micro_step):
+        """Length of the gradient-accumulation window this micro-step belongs to (the loss of each
+        of its micro-steps is divided by it): ``grad_accum_steps``, or what is left of the epoch."""
+        A = self.grad_accum_steps
+        if self.steps_this_epoch is None:
+            return A
+        start = micro_step - micro_step % A
+        return max(1, min(A, self.steps_this_epoch - start))
 
     def _progress(self, iterable, desc=None):
         if self.progress and _tqdm is not None and self.world_rank == 0:
@@ -217,7 +241,9 @@ class Trainer(object):
     def _maybe_inject_fault(self):
         """Kill-a-rank test hook: FAULT_INJECT_STEP / FAULT_INJECT_RANK."""
         s = os.environ.get("FAULT_INJECT_STEP")
-        if s is not None and int(s) == self.global_step and \
+        restarted = max(int(os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") or 0),
+                        int(os.environ.get("DTP_RESTART_COUNT", "0") or 0)) > 0
+        if s is not None and not restarted and int(s) == self.global_step and \
                 int(os.environ.get("FAULT_INJECT_RANK", "0")) == self.world_rank:
             self.log("fault injection: rank %d exits at step %d" % (self.world_rank, self.global_step), "error")
             os._exit(17)
@@ -230,9 +256,20 @@ class Trainer(object):
         return 1
 
     def _reduce_means(self, sums, count):
-        """Sample-weighted means over all ranks: one small all-reduce of (sums..., count)."""
+        """Sample-weighted means over all ranks: one small all-reduce of (sums..., count).
+
+        The metric names are agreed on first (union over ranks, fixed order): a rank whose shard
+        was empty (``len(val) < world``) has no names of its own and must still send a vector of
+        the same length as its peers — it contributes zeros and a zero count."""
         keys = list(sums.keys())
-        vals = comm.all_reduce_scalars([_to_float(sums[k]) for k in keys] + [float(count)])
+        if self.world_size > 1:
+            seen = []
+            for ks in comm.all_gather_object(keys):
+                for k in ks:
+                    if k not in seen:
+                        seen.append(k)
+            keys = seen
+        vals = comm.all_reduce_scalars([_to_float(sums[k]) if k in sums else 0.0 for k in keys] + [float(count)])
         total = max(vals[-1], 1.0)
         return {k: v / total for k, v in zip(keys, vals[:-1])}
 
@@ -254,6 +291,7 @@ class Trainer(object):
                                                  else metrics[key] <= bf["value"])
                 if better:
                     bf["epoch"], bf["value"], bf["metrics"] = epoch, metrics[key], copy.deepcopy(metrics)
+                    self.model.consolidate()     # every rank takes this branch: metrics are all-reduced
                     if self.world_rank == 0:
                         self._save_snapshot(epoch, name="best")
                 self.log(RULE)
@@ -272,6 +310,12 @@ class Trainer(object):
             self.log("[GPU%d] Epoch %d/%d" % (self.world_rank, epoch + 1, self.max_epoch))
             sums, count = None, 0
             self.meter.start()
+            try:
+                self.steps_this_epoch = len(self.train_dataloader)
+                if self.max_steps_per_epoch is not None:
+                    self.steps_this_epoch = min(self.steps_this_epoch, self.max_steps_per_epoch)
+            except TypeError:       # a loader without a length: windows cannot be flushed at the end
+                self.steps_this_epoch = None
             loop = self._progress(DevicePrefetcher(self.train_dataloader, self.device))
             it, i = iter(loop), -1
             data_wait_s = step_host_s = 0.0
@@ -312,6 +356,8 @@ class Trainer(object):
                 self.log("THE NEXT LEARNING RATE VALUE IS %s" % self.scheduler.get_last_lr()[0])
 
             # snapshots (reference :163-172): rank 0 writes, everyone waits
+            if self.have_validate or epoch % self.save_period == 0:
+                self.model.consolidate()         # collective: sharded optimizer state -> complete on every rank
             if self.world_rank == 0:
                 if self.have_validate:
                     self._save_snapshot(epoch + 1, name="last")
@@ -335,8 +381,11 @@ class Trainer(object):
                     self.log(msg)
                 self.log("THROUGHPUT: %.1f images/sec (%d images, %.2fs)" % (ips, self.meter.items, self.meter.elapsed))
                 exposed = (reducer.exposed_ms_total() - exposed0) if reducer is not None else 0.0
+                phases = self.step_timer.summary()
+                self.step_timer.reset()
                 self._write_metrics(dict(
                     epoch=epoch + 1, images_per_sec=ips, steps=steps_done,
+                    **{"gpu_%s_ms_per_step" % k: v["total_ms"] / steps_done for k, v in phases.items()},
                     data_wait_ms_per_step=1e3 * data_wait_s / steps_done,      # host blocked on the loader
                     host_step_ms_per_step=1e3 * step_host_s / steps_done,      # host time inside train_step
                     allreduce_exposed_ms_per_step=exposed / steps_done,        # GPU idle waiting for buckets

@@ -5,10 +5,14 @@ the keys ``epoch``, ``model_state_dict`` (unwrapped module, fp32), ``optimizer_s
 ``scheduler_state_dict`` under ``<save_folder>/weights/<name>.pth``.
 
 Additions that old readers ignore: ``best_fitness`` (quirk #7), ``rng_state``,
-``framework``.  Writes are atomic (tmp + ``os.replace``).  Loading uses ``weights_only=True``
-first (nothing in our own files needs unpickling arbitrary objects) and maps to CPU; the caller
-moves state to the training device (fixes quirk #4).
+``framework``.  Writes are atomic (tmp + ``os.replace``).  Loading ALWAYS uses
+``weights_only=True`` — a snapshot is data, never code: the one non-tensor type our files carry
+(``collections.Counter`` for ``MultiStepLR.milestones``) is allow-listed explicitly, and a file the
+safe loader refuses is an error unless the caller opts in with ``trusted=True`` (a file they wrote
+themselves with an older torch).  State maps to CPU; the caller moves it to the training device
+(fixes quirk #4).
 """
+import collections
 import os
 
 import torch
@@ -32,12 +36,16 @@ def save_snapshot(path, epoch, model, optimizer, scheduler, extra=None):
     return path
 
 
-def load_snapshot(path):
-    try:
-        snap = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        # our own files may carry python scalars / Counters inside scheduler state
+def load_snapshot(path, trusted=False):
+    """Load a snapshot without executing anything from the file.  ``trusted=True`` (explicit, for
+    files you wrote yourself) allows full unpickling."""
+    if trusted:
         snap = torch.load(path, map_location="cpu", weights_only=False)
+    else:
+        with torch.serialization.safe_globals([collections.Counter]):
+            snap = torch.load(path, map_location="cpu", weights_only=True)
+    if not isinstance(snap, dict):
+        raise TypeError("snapshot %s does not hold a dict" % path)
     for k in REQUIRED_KEYS:
         if k not in snap:
             raise KeyError("snapshot %s lacks key %r" % (path, k))

@@ -47,6 +47,22 @@ class StepTimer(object):
             ev.record()
             self._pairs.setdefault(name, []).append((self._open.pop(name), ev))
 
+    def reset(self):
+        self._open, self._pairs = {}, {}
+
+    def phase(self, name):
+        """``with timer.phase("fwd"): ...`` — a pair of HIP events around the block (no host sync)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self.begin(name)
+            try:
+                yield
+            finally:
+                self.end(name)
+        return _cm()
+
     def summary(self):
         if not self.enabled:
             return {}

@@ -44,11 +44,43 @@ def parse_args(argv=None):
     ap.add_argument("--device-cache", action="store_true",
                     help="materialise the dataset once on the GPU and gather batches there (fits-in-HBM datasets)")
     ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (1 process)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="reduce-scatter + per-bucket sharded optimizer + all-gather instead of all-reduce")
+    ap.add_argument("--nproc", type=int, default=0,
+                    help="self-launch this many local ranks (one per GPU) without torchrun; 0: run in this process")
+    ap.add_argument("--max-restarts", type=int, default=0,
+                    help="with --nproc: relaunch a failed job this many times; restarted jobs resume from last.pth")
+    ap.add_argument("--no-auto-resume", action="store_true",
+                    help="do not pick up <save-folder>/weights/last.pth after an elastic / launcher restart")
     return ap.parse_args(argv)
+
+
+def restart_count():
+    """How often this job has been restarted by its launcher (torchrun's elastic agent exports
+    TORCHELASTIC_RESTART_COUNT, the self-launcher DTP_RESTART_COUNT)."""
+    return max(int(os.environ.get("TORCHELASTIC_RESTART_COUNT", "0") or 0),
+               int(os.environ.get("DTP_RESTART_COUNT", "0") or 0))
+
+
+def pick_snapshot(args):
+    """Explicit --snapshot wins; otherwise a RESTARTED job resumes from the last snapshot it wrote
+    (the decision is taken inside each restarted worker, not once by the
+    shell before the first launch)."""
+    if args.snapshot or args.no_auto_resume:
+        return args.snapshot
+    last = os.path.join(args.save_folder, "weights", "last.pth")
+    if restart_count() > 0 and os.path.isfile(last):
+        return last
+    return None
 
 
 if __name__ == "__main__":
     args = parse_args()
+    if args.nproc > 0 and "WORLD_SIZE" not in os.environ:
+        # self-launch (reference run.sh:9-14 uses torchrun): this parent never touches the GPU
+        import sys
+        from distributed_training_pytorch_amd.launch import spawn_workers
+        sys.exit(spawn_workers(os.path.abspath(__file__), sys.argv[1:], args.nproc, max_restarts=args.max_restarts))
     logger = Logger("VGG16", file="%s/logfile.log" % args.save_folder)
 
     backend = args.backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -68,7 +100,7 @@ if __name__ == "__main__":
                              save_best_for=("accuracy", "geq"),
                              save_period=args.save_period,
                              save_folder=args.save_folder,
-                             snapshot_path=args.snapshot,
+                             snapshot_path=pick_snapshot(args),
                              logger=logger,
                              lr=args.lr,
                              batch_norm=args.batch_norm, fp8_classifier=args.fp8_classifier, uint8_input=args.uint8_input,
@@ -77,6 +109,7 @@ if __name__ == "__main__":
                              num_workers=args.num_workers,
                              max_steps_per_epoch=args.steps,
                              progress=not args.no_progress, use_hip_graph=args.hip_graph, cache_dataset_on_device=args.device_cache,
+                             shard_optimizer=args.shard_optimizer,
                              metrics_file="%s/metrics.jsonl" % args.save_folder)
 
     trainer.train()

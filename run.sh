@@ -20,16 +20,14 @@ export NCCL_DEBUG="${NCCL_DEBUG:-WARN}"                       # INFO prints topo
 export NCCL_MIN_NCHANNELS="${NCCL_MIN_NCHANNELS:-32}"         # spread rings over all xGMI links
 export HSA_ENABLE_IPC_MODE_LEGACY="${HSA_ENABLE_IPC_MODE_LEGACY:-0}"   # dmabuf IPC (required on this pool)
 export TORCH_NCCL_ASYNC_ERROR_HANDLING="${TORCH_NCCL_ASYNC_ERROR_HANDLING:-1}"
-export TORCH_NCCL_TRACE_BUFFER_SIZE="${TORCH_NCCL_TRACE_BUFFER_SIZE:-2000}"   # flight recorder entries
+export TORCH_FR_BUFFER_SIZE="${TORCH_FR_BUFFER_SIZE:-2000}"                 # flight recorder entries (reference run.sh:8)
 export DTP_PG_TIMEOUT_S="${DTP_PG_TIMEOUT_S:-600}"
 if [ "${NNODES}" -gt 1 ]; then
   export NCCL_SOCKET_IFNAME="${NCCL_SOCKET_IFNAME:-eno1}"     # bootstrap / inter-node interface
 fi
 
-EXTRA=()
-if [ "${MAX_RESTARTS}" -gt 0 ] && [ -f runs/weights/last.pth ]; then
-  EXTRA+=(--snapshot runs/weights/last.pth)                  # auto-resume after a restart
-fi
+# Auto-resume is decided INSIDE each (re)started worker: main.py picks up
+# <save-folder>/weights/last.pth when TORCHELASTIC_RESTART_COUNT > 0 (see main.py: pick_snapshot).
 
 exec python -m torch.distributed.run \
   --nproc_per_node="${NGPU}" \
@@ -38,4 +36,4 @@ exec python -m torch.distributed.run \
   --master_addr="${MASTER_ADDR}" \
   --master_port="${MASTER_PORT}" \
   --max_restarts="${MAX_RESTARTS}" \
-  main.py "${EXTRA[@]}" "$@"
+  main.py "$@"

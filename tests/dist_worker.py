@@ -150,7 +150,8 @@ def scenario_trainer(out):
     comm.barrier()
     files = sorted(os.listdir(os.path.join(save, "weights")))
     assert files == ["best.pth", "last.pth"], files
-    snap = torch.load(os.path.join(save, "weights", "last.pth"), map_location="cpu", weights_only=False)
+    from distributed_training_pytorch_amd.utils.checkpoint import load_snapshot
+    snap = load_snapshot(os.path.join(save, "weights", "last.pth"))      # the safe (weights_only) loader
     assert snap["epoch"] == 2 and "best_fitness" in snap
     assert abs(tr.scheduler.get_last_lr()[0] - 0.001) < 1e-12          # one milestone passed
     # resume: continues at epoch 2 with the decayed LR and the stored best fitness (quirks #4, #7)
@@ -168,6 +169,98 @@ def scenario_trainer(out):
     assert not os.path.exists(os.path.join(save, "logfile.log.rank1"))
 
 
+def scenario_sharded(out):
+    """Sharded mode (reduce-scatter -> optimizer on the owned slice -> all-gather, per bucket) must
+    train exactly like all-reduce + replicated optimizer: same parameters bit for bit after several
+    steps (gloo's reduce-scatter stand-in is its all-reduce, so the sums are the same sums), with
+    gradient accumulation, for SGD and AdamW; consolidate() completes state on every rank."""
+    from distributed_training_pytorch_amd.models import FusedModel
+    from distributed_training_pytorch_amd.ops.layers import Linear
+    from distributed_training_pytorch_amd.ops.optim import FusedAdamW, FusedSGD
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    class Net(FusedModel):
+        def __init__(self):
+            super().__init__()
+            self.a = Linear(16, 96, relu=True)
+            self.b = Linear(96, 136, relu=True)
+            self.b2 = Linear(136, 120, relu=True)
+            self.c = Linear(120, 5, out_fp32=True)
+            self.finalize()
+
+        def forward(self, x):
+            return self.c(self.b2(self.b(self.a(self.prepare_input(x)))))
+
+    g = torch.Generator().manual_seed(7)
+    X = torch.randn(6, 8 * world, 16, generator=g)
+    Y = torch.randint(0, 5, (6, 8 * world), generator=g)
+
+    def run(opt_cls, sharded, **okw):
+        torch.manual_seed(4321)
+        net = Net()
+        opt = opt_cls(net, **okw)
+        # the reference run uses the SAME bucket ranges (snapped to world * 64 elements): gloo's ring
+        # all-reduce sums an element in an order that depends on its position in the message, so
+        # only equal messages give equal bits at world 4
+        dp = DataParallel(net, bucket_cap_mb=0.02, first_bucket_mb=0.004,
+                          shard_optimizer=opt if sharded else None,
+                          bucket_align_elems=None if sharded else world * 64)
+        assert dp.reducer.sharded == sharded
+        assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
+        if sharded:
+            for b in dp.reducer.buckets:
+                assert (b.hi - b.lo) % (world * 64) == 0, (b.lo, b.hi)
+            cover = sorted((b.lo, b.hi) for b in dp.reducer.buckets)
+            assert cover[0][0] == 0 and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+            assert cover[-1][1] >= net.param_arena.total
+        for it in range(6):
+            xs, ys = X[it, rank::world], Y[it, rank::world]
+            opt.zero_grad()
+            if it % 3 == 2:                                   # a two-micro-step accumulation window
+                with dp.no_sync():
+                    (nn.functional.cross_entropy(dp(xs[:4]), ys[:4]) / 2).backward()
+                (nn.functional.cross_entropy(dp(xs[4:]), ys[4:]) / 2).backward()
+            else:
+                nn.functional.cross_entropy(dp(xs), ys).backward()
+            opt.step()
+        dp.consolidate()
+        sd = opt.state_dict()
+        state = torch.cat([v.reshape(-1) for st in sd["state"].values() for v in st.values() if torch.is_tensor(v)])
+        return net.param_arena.flat_master[:net.param_arena.total].clone(), state, dp
+
+    for opt_cls, okw in ((FusedSGD, dict(lr=0.05, momentum=0.9, weight_decay=1e-4)),
+                         (FusedAdamW, dict(lr=1e-3, weight_decay=1e-2))):
+        ref_w, ref_s, _ = run(opt_cls, False, **okw)
+        sh_w, sh_s, dp = run(opt_cls, True, **okw)
+        assert torch.equal(ref_w, sh_w), "%s: sharded parameters differ (max %g)" % (
+            opt_cls.__name__, float((ref_w - sh_w).abs().max()))
+        assert torch.equal(ref_s, sh_s), "%s: consolidated optimizer state differs" % opt_cls.__name__
+        assert _allclose_across_ranks(sh_w) and _allclose_across_ranks(sh_s)
+        try:                                                  # step() without a synchronised backward: loud
+            dp.reducer.opt.step()
+            raise AssertionError("sharded step() without a backward pass must raise")
+        except RuntimeError:
+            pass
+
+
+def scenario_small_val(out):
+    """len(val) < world: a rank with an EMPTY validation shard must still take part in the metric
+    reduction with a vector of the right length (was: size-mismatched collective)."""
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+    world = dist.get_world_size()
+    tr = ExampleTrainer(train_path="synthetic:%d" % (4 * world), val_path="synthetic:1", labels=["a", "b", "c"],
+                        height=32, width=32, max_epoch=1, batch_size=2 * world, pin_memory=False, have_validate=True,
+                        save_best_for=("accuracy", "geq"), save_period=1, save_folder=os.path.join(out, "runs"),
+                        progress=False, lr=0.01, max_steps_per_epoch=1)
+    tr.model.eval()
+    m = tr.validate()
+    assert set(m) == {"accuracy"} and m["accuracy"] in (0.0, 1.0), m      # one sample in total
+    vals = [None] * world
+    dist.all_gather_object(vals, m)
+    assert all(v == vals[0] for v in vals), vals
+    tr.train()                                                             # the epoch loop runs through it too
+
+
 def scenario_fault(out):
     """Kill-a-rank: rank 1 dies at global step 1; rank 0 must fail fast (timeout), not hang."""
     from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
@@ -183,7 +276,7 @@ if __name__ == "__main__":
     scenario, out = sys.argv[1], sys.argv[2]
     penv.ddp_setup("gloo", timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
     {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault,
-     "gpu_shared": scenario_gpu_shared}[scenario](out)
+     "gpu_shared": scenario_gpu_shared, "sharded": scenario_sharded, "small_val": scenario_small_val}[scenario](out)
     comm.barrier()
     open(os.path.join(out, "ok.%d" % dist.get_rank()), "w").write("ok")
     penv.destroy_process()

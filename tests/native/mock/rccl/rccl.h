@@ -18,3 +18,7 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
                            ncclComm_t comm, hipStream_t stream);
 ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t dt, int root,
                            ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, ncclDataType_t dt, ncclRedOp_t op,
+                               ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t dt, ncclComm_t comm,
+                           hipStream_t stream);

@@ -62,6 +62,21 @@ ncclResult_t ncclBroadcast(const void*, void*, size_t n, ncclDataType_t, int roo
   return ncclSuccess;
 }
 
+ncclResult_t ncclReduceScatter(const void* s, void* r, size_t n, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c,
+                               hipStream_t st) {
+  // in-place contract: recv == send + rank * recvcount * elem
+  const size_t esz = dt == ncclBfloat16 ? 2 : 4;
+  assert(c && st && st->non_blocking && (const char*)r == (const char*)s + (size_t)c->rank * n * esz);
+  logc("reducescatter:" + std::to_string(st->id) + ":" + std::to_string(n) + ":" + std::to_string((int)op));
+  return ncclSuccess;
+}
+ncclResult_t ncclAllGather(const void* s, void* r, size_t n, ncclDataType_t dt, ncclComm_t c, hipStream_t st) {
+  const size_t esz = dt == ncclBfloat16 ? 2 : 4;
+  assert(c && st && st->non_blocking && (const char*)s == (const char*)r + (size_t)c->rank * n * esz);
+  logc("allgather:" + std::to_string(st->id) + ":" + std::to_string(n));
+  return ncclSuccess;
+}
+
 // ---- unit under test -----------------------------------------------------------------------------
 extern "C" {
 int dtp_rccl_unique_id(void* out, int out_bytes);
@@ -81,12 +96,75 @@ int dtp_reducer_set_sync(void* h, int on);
 int dtp_reducer_stats(void* h, unsigned long long* passes, unsigned long long* launched,
                       unsigned long long* duplicates);
 int dtp_reducer_destroy(void* h);
+int dtp_reducer_set_shard(void* h, int opt_kind, void* sgd_fn, void* adamw_fn, int n_buckets, void* const* master,
+                          void* const* grad, void* const* s1, void* const* s2, void* const* lp,
+                          const size_t* slice_counts, void* const* wbase, int wkind, int world);
+int dtp_reducer_begin_pass(void* h, const float* hyper, int n_hyper, const int* iargs, int n_iargs);
 }
 
 static int count_calls(const char* prefix) {
   int n = 0;
   for (const auto& c : g_log.calls) n += c.rfind(prefix, 0) == 0;
   return n;
+}
+
+// stand-in for csrc/optim.hip's dtp_sgd_flat: records what the scheduler asked for
+static int fake_sgd(float* p, const void* g, int g_bf16, float* mom, void* lp, size_t n, float lr, float momentum,
+                    float dampening, float wd, float grad_scale, int nesterov, int first_step, hipStream_t s) {
+  assert(p && g && mom && lp && s && s->non_blocking && grad_scale == 1.0f && dampening == 0.0f && wd == 1e-4f);
+  logc("sgd:" + std::to_string(s->id) + ":" + std::to_string(n) + ":" + std::to_string(g_bf16) + ":" +
+       std::to_string(lr == 0.5f && momentum == 0.9f) + ":" + std::to_string(nesterov) + std::to_string(first_step));
+  return 0;
+}
+
+// sharded mode: per bucket reduce-scatter -> optimizer on the owned slice -> all-gather, all on the
+// comm stream, one producer event per bucket, one consumer wait per pass (rank 1 of world 4)
+static void test_sharded_scheduler(void* transport, MockStream* compute) {
+  static float master[256], mom[256];
+  static unsigned short grad[256], lp[256];
+  const int rank = 1, world = 4;
+  // two buckets: elements [128, 256) and [0, 128) of the arena (reverse registration order)
+  void* ptrs[2] = {grad + 128, grad};
+  size_t counts[2] = {128, 128};
+  int kinds[2] = {1, 1};
+  int offs[3] = {0, 1, 2};
+  int idx[2] = {1, 0};                                      // param 0 -> bucket 1, param 1 -> bucket 0
+  void* r = dtp_reducer_create(transport, 2, ptrs, counts, kinds, 2, offs, idx);
+  assert(r);
+  const size_t S = 128 / world;
+  void* m_[2] = {master + 128 + rank * S, master + rank * S};
+  void* g_[2] = {grad + 128 + rank * S, grad + rank * S};
+  void* s1_[2] = {mom + 128 + rank * S, mom + rank * S};
+  void* lp_[2] = {lp + 128 + rank * S, lp + rank * S};
+  void* wb_[2] = {lp + 128, lp};
+  size_t sc[2] = {S, S};
+  size_t bad[2] = {S, S + 4};
+  assert(dtp_reducer_set_shard(r, 1, nullptr, nullptr, 2, m_, g_, s1_, nullptr, lp_, sc, wb_, 1, world) == -3);
+  assert(dtp_reducer_set_shard(r, 1, (void*)fake_sgd, nullptr, 2, m_, g_, s1_, nullptr, lp_, bad, wb_, 1, world) == -5);
+  assert(dtp_reducer_set_shard(r, 1, (void*)fake_sgd, nullptr, 2, m_, g_, s1_, nullptr, lp_, sc, wb_, 1, world) == 0);
+  g_log.calls.clear();
+  assert(dtp_reducer_mark_ready(r, 1, compute) < 0);        // pass not armed: refused, nothing launched
+  assert(count_calls("reducescatter") == 0);
+  void* r2 = dtp_reducer_create(transport, 2, ptrs, counts, kinds, 2, offs, idx);   // fresh counters
+  assert(dtp_reducer_destroy(r) == 0);
+  r = r2;
+  assert(dtp_reducer_set_shard(r, 1, (void*)fake_sgd, nullptr, 2, m_, g_, s1_, nullptr, lp_, sc, wb_, 1, world) == 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    const float hyper[4] = {0.5f, 0.9f, 0.0f, 1e-4f};
+    const int iargs[2] = {0, pass == 0};
+    assert(dtp_reducer_begin_pass(r, hyper, 4, iargs, 2) == 0);
+    g_log.calls.clear();
+    assert(dtp_reducer_mark_ready(r, 1, compute) == 1);     // bucket 0 complete
+    assert(g_log.calls.size() == 5);
+    assert(g_log.calls[0] == "record:1" && g_log.calls[1] == "wait:100:on:1");
+    assert(g_log.calls[2] == "reducescatter:100:32:4");
+    assert(g_log.calls[3] == std::string("sgd:100:32:1:1:0") + (pass == 0 ? "1" : "0"));
+    assert(g_log.calls[4] == "allgather:100:32");
+    assert(dtp_reducer_finalize(r, compute) == 1);          // bucket 1 never became ready: launched here
+    assert(count_calls("reducescatter") == 2 && count_calls("sgd") == 2 && count_calls("allgather") == 2);
+    assert(g_log.calls.back() == "wait:1:on:100");
+  }
+  assert(dtp_reducer_destroy(r) == 0);
 }
 
 // bucket scheduler: params 0,1 -> bucket 0; param 2 -> buckets 1 and 2 (split); param 3 -> bucket 2
@@ -177,6 +255,7 @@ int main() {
   assert(dtp_rccl_stats(t, &launched, &bytes) == 0 && launched == 7000 && bytes == want_bytes);
 
   test_scheduler(t, &compute);
+  test_sharded_scheduler(t, &compute);
   g_log.calls.clear();
   assert(dtp_rccl_broadcast(t, buf, 64, 0, 0, &compute) == 0);
   assert(g_log.calls.size() == 5 && g_log.calls[2] == "broadcast:100:64:0" && g_log.calls[4] == "wait:1:on:100");

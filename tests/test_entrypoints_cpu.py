@@ -70,7 +70,8 @@ def test_trainer_single_process_flow_and_eval(tmp_path, capsys):
     tr.train()
     files = sorted(os.listdir(os.path.join(save, "weights")))
     assert files == ["best.pth", "last.pth"], files
-    snap = torch.load(os.path.join(save, "weights", "last.pth"), map_location="cpu", weights_only=False)
+    from distributed_training_pytorch_amd.utils.checkpoint import load_snapshot
+    snap = load_snapshot(os.path.join(save, "weights", "last.pth"))      # the safe (weights_only) loader
     assert sorted(k for k in snap if k in ("epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict")) \
         == ["epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"]
     assert snap["epoch"] == 2 and len(snap["model_state_dict"]) == 32
@@ -103,3 +104,44 @@ def test_trainer_single_process_flow_and_eval(tmp_path, capsys):
                                       "--image-size", "32", "--device", "cpu", "--labels", "a,b,c", "--batch-size", "4"])
     assert n == 12 and 0.0 <= acc1 <= acck <= 1.0
     assert "EVALUATION ACCURACY RESULTS: TOP-1=" in capsys.readouterr().out
+
+
+def test_grad_accumulation_flushes_the_trailing_short_window(tmp_path):
+    """3 steps per epoch with grad_accum_steps=2: the third micro-batch is a window of its own —
+    synchronised, stepped with its loss scaled by 1/1 (not 1/2) — instead of being silently
+    dropped at the epoch boundary; equal to the hand-rolled schedule on the same batches."""
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+
+    class NoDropTrainer(ExampleTrainer):
+        def build_model(self):
+            return VGG16(3, len(self.labels), True, dropout=0.0)
+
+    kw = dict(train_path="synthetic:12", val_path="synthetic:4", labels=["a", "b", "c"], height=32, width=32,
+              batch_size=4, pin_memory=False, have_validate=False, save_period=1, progress=False, lr=0.01,
+              device="cpu", max_epoch=1)
+    torch.manual_seed(11)
+    tr = NoDropTrainer(save_folder=str(tmp_path / "a"), grad_accum_steps=2, **kw)
+    assert [tr.accum_window(i) for i in range(3)] == [2, 2, 2]          # before an epoch: no length known
+    tr.train()
+    assert tr.steps_this_epoch == 3
+    assert [tr.should_sync(i) for i in range(3)] == [False, True, True]
+    assert [tr.accum_window(i) for i in range(3)] == [2, 2, 1]
+    assert tr.optimizer._steps == 2                                      # window [0, 1] and the flushed window [2]
+
+    torch.manual_seed(11)
+    ref = NoDropTrainer(save_folder=str(tmp_path / "b"), grad_accum_steps=1, **kw)
+    ref.train_dataloader.sampler.set_epoch(0)
+    batches = list(ref.train_dataloader)
+    assert len(batches) == 3
+    model, opt, crit = ref.model, ref.optimizer, ref.criterion
+    model.train()
+    opt.zero_grad()
+    (crit(model(batches[0][0]), batches[0][1]) / 2).backward()
+    (crit(model(batches[1][0]), batches[1][1]) / 2).backward()
+    opt.step()
+    opt.zero_grad()
+    crit(model(batches[2][0]), batches[2][1]).backward()
+    opt.step()
+    a, b = tr.raw_model.param_arena.flat_master, ref.raw_model.param_arena.flat_master
+    assert torch.allclose(a, b, atol=1e-7), float((a - b).abs().max())

@@ -242,7 +242,7 @@ def test_snapshot_schema_atomic_write_and_roundtrip(tmp_path):
     path = str(tmp_path / "weights" / "last.pth")
     ckpt.save_snapshot(path, 7, m1, o1, s1, extra=dict(best_fitness=dict(epoch=3, value=0.5, metrics={"accuracy": 0.5})))
     assert os.listdir(os.path.dirname(path)) == ["last.pth"]        # no temp files left behind
-    snap = torch.load(path, map_location="cpu", weights_only=False)
+    snap = ckpt.load_snapshot(path)                                   # weights_only=True + Counter allow-list
     assert set(["epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"]) <= set(snap)
     assert snap["epoch"] == 7 and snap["best_fitness"]["epoch"] == 3
     assert snap["scheduler_state_dict"]["gamma"] == 0.1
@@ -250,6 +250,14 @@ def test_snapshot_schema_atomic_write_and_roundtrip(tmp_path):
     stock.load_state_dict(snap["model_state_dict"])                  # reference-style consumer (eval.py:48-49)
     snap2 = ckpt.load_snapshot(path)
     assert snap2["epoch"] == 7
+    # a file that needs arbitrary unpickling is refused (never silently retried with the unsafe
+    # loader); the explicit opt-in for self-written files still reads it
+    evil = str(tmp_path / "evil.pth")
+    torch.save(dict(epoch=1, model_state_dict={}, optimizer_state_dict={}, scheduler_state_dict={},
+                    obj=os.path.join), evil)                          # a function reference: code, not data
+    with pytest.raises(Exception):
+        ckpt.load_snapshot(evil)
+    assert ckpt.load_snapshot(evil, trusted=True)["epoch"] == 1
     bad = str(tmp_path / "bad.pth")
     torch.save(dict(epoch=1), bad)
     with pytest.raises(KeyError):
