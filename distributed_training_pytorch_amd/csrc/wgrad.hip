@@ -612,6 +612,11 @@ static int launch_wg8(const WgradParams& p0, int nsplit, hipStream_t stream) {
   return DTP_CHECK_LAUNCH();
 }
 
+// second-generation kernels (csrc/wgrad2.hip): cfg 8 = 256x256 tile, cfg 9 = 128x128 tile
+extern "C" int dtp_wgrad_tt2_launch(const void* dY, const void* X, void* out, float* partial, int K, int M, int Ntot,
+                                    int C, int taps, int H, int W, int lda, int ldb, int out_fp32, float beta,
+                                    int nsplit, int ksteps_total, int ksteps_per_split, int cfg, hipStream_t stream);
+
 // taps == 9: X is NHWC [K = N*H*W][C], dW is [M][9*C].  taps == 1: X is [K][ldb], dW is [M][Ntot].
 extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* partial, const void* zero_page,
                             int K, int M, int Ntot, int C, int taps, int H, int W, int lda, int ldb,
@@ -648,6 +653,11 @@ extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* par
     case 7: rc = t9 ? launch_wg<128, 128, 2, 2, true, true>(p, nsplit, stream)
                     : launch_wg<128, 128, 2, 2, false, true>(p, nsplit, stream); break;
     case 5: rc = t9 ? launch_wg8<true>(p, nsplit, stream) : launch_wg8<false>(p, nsplit, stream); break;
+    case 8: case 9:
+      if (t9 && (C % (cfg == 8 ? 256 : 128))) return -20;
+      rc = dtp_wgrad_tt2_launch(dY, X, out, partial, K, M, Ntot, C, taps, H, W, lda, ldb, out_fp32, beta, nsplit,
+                                p.ksteps_total, p.ksteps_per_split, cfg - 8, stream);
+      break;
     default: return -16;
   }
 #undef DTP_WG

@@ -28,6 +28,11 @@ def _close(a, b, rtol, atol, name):
     bad = (err > tol).float().mean().item()
     assert bad < 1e-4, "%s: %.5f%% elements out of tolerance, max err %.4g (ref max %.4g)" % (
         name, bad * 100, err.max().item(), b.abs().max().item())
+    # hard cap: the few elements allowed past the tolerance (bf16 rounding at a boundary) may miss it
+    # by a small factor only — a stale LDS row or a dropped K-tile is wrong by O(1) and must fail
+    worst = (err / tol).max().item()
+    assert worst < 4.0, "%s: an element is %.1fx over its tolerance (max err %.4g, ref max %.4g)" % (
+        name, worst, err.max().item(), b.abs().max().item())
 
 
 def _ref_conv(x_nhwc, w_flat, bias, relu):
@@ -135,7 +140,7 @@ def test_conv3x3_wgrad(shape, out_dtype):
     _close(out, 2 * ref, 3e-2, 3e-2 * scale, "wgrad-acc%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv3x3_wgrad_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(4)
@@ -504,11 +509,18 @@ def test_fp8_quant_and_linear_forward(shape):
     assert rel < 0.06, rel
 
 
-@pytest.mark.parametrize("shape", [(2, 28, 28, 512, 512), (3, 7, 9, 256, 512), (1, 56, 56, 256, 256)])
-def test_wgrad_8phase_schedule(shape):
-    """cfg 5 (8-phase counted-vmcnt 256x256 weight-gradient kernel) on conv shapes incl. K tails,
-    bf16 output with beta accumulation, and the linear (taps == 1) form with M / N tails."""
+@pytest.mark.parametrize("cfg", [5, 8, 9])
+@pytest.mark.parametrize("shape", [(2, 28, 28, 512, 512), (3, 7, 9, 256, 512), (1, 56, 56, 256, 256),
+                                   (70, 4, 4, 256, 256), (2, 224, 9, 128, 384)])
+def test_wgrad_8phase_schedule(shape, cfg):
+    """The hand-scheduled weight-gradient kernels — cfg 5 (8-phase counted-vmcnt, wgrad.hip) and
+    cfg 8 / 9 (wgrad2.hip: asm transposed reads, descriptor staging with hardware zero fill, ballot
+    border masks) — on conv shapes incl. K tails, images smaller than one K-step (4x4: several
+    wraps of the row tracker per step), W < 64 < H, bf16 output with beta accumulation, and the
+    linear (taps == 1) form with M / N tails."""
     k = _k()
+    if shape[3] % 256 and cfg != 9:
+        pytest.skip("256-wide tiles need C % 256 == 0")
     N, H, W, C, Co = shape
     torch.manual_seed(14)
     x = _rand(N, H, W, C)
@@ -518,7 +530,7 @@ def test_wgrad_8phase_schedule(shape):
     (gw,) = torch.autograd.grad(F.conv2d(xr, wref, padding=1), wref, dy.float().permute(0, 3, 1, 2))
     ref = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
     for nsplit, dt, beta in ((1, torch.float32, 0.0), (5, torch.float32, 1.0), (2, BF16, 1.0)):
-        k._overrides["wgrad"] = lambda M, Cc, taps, ks: (5, nsplit)
+        k._overrides["wgrad"] = lambda M, Cc, taps, ks: (cfg, nsplit)
         try:
             out = torch.full((Co, 9 * C), 0.5, device="cuda", dtype=dt)
             k.conv3x3_wgrad(dy, x, out, beta=beta)
@@ -529,7 +541,7 @@ def test_wgrad_8phase_schedule(shape):
     M, Kin, Nout = 200, 520, 300
     xl = _rand(M, Kin)
     dl = _rand(M, 320, scale=0.1)
-    k._overrides["wgrad"] = lambda Mm, Cc, taps, ks: (5, 2)
+    k._overrides["wgrad"] = lambda Mm, Cc, taps, ks: (cfg, 2)
     try:
         gl = torch.empty((Nout, Kin), device="cuda")
         k.linear_wgrad(dl, xl, gl, n_valid=Nout)
