@@ -70,11 +70,11 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #pragma unroll
       for (int k = 0; k < 4; ++k) wf[t][k] = *(const bf16x8_t*)(wbase + (t * 64 + k * 16) * 2);
   }
-  // accumulator row (cout within the wave's 32) of register r: (r&3) + 8*(r>>2) + 4*hb
-  float bias_r[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-    bias_r[r] = p.bias ? p.bias[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hb] : 0.f;
+  // accumulator row (cout within the wave's 32) of register r: (r&3) + 8*(r>>2) + 4*hb.  The bias
+  // sits in LDS and is added after the MFMAs: 16 registers less than a register-resident copy, which
+  // lets the fragment reads run one tap (4 x ds_read_b128) ahead of the MFMAs.
+  float* lBias = (float*)(smem + 4 * X_SLOT + NW * 2048 + O * 2 * 32);
+  if (tid < O) lBias[tid] = p.bias ? p.bias[tid] : 0.f;
 
   // ---- ring staging geometry
   const int xr = lane >> 3, xpc = lane & 7;
@@ -95,12 +95,12 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
     }
   };
   // fragment read geometry: B operand, lane = (col px = l31, k = 8*hb + j); ring position px+dx+1
-  int xbase[3], xsw[3];
+  int xoff[3][4];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int pos = l31 + d;
-    xbase[d] = pos * 128;
-    xsw[d] = (pos >> 1) & 7;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xoff[d][k] = pos * 128 + ((((2 * k + hb) ^ ((pos >> 1) & 7))) << 4);
   }
   char* myO = lO + wave * 2048;
   const bool px_ok = (w0 + l31) < p.W;
@@ -123,18 +123,40 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
     }
     f32x16_t acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias_r[r];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // tap t+1's four fragment reads are issued before tap t's four MFMAs; asm reads with counted
+    // waits (hipcc's own placement waited lgkmcnt(0) at every second tap)
+    u32x4_t xf[2][4];
+    const unsigned lx0 = lds_addr(lX);
+#define C64_RD(buf, t)                                                                          \
+  {                                                                                             \
+    const unsigned s_ = lx0 + ((h + (t) / 3) & 3) * X_SLOT;                                     \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) DTP_DSR128(xf[buf][k], s_ + xoff[(t) % 3][k]); \
+  }
+    __builtin_amdgcn_sched_barrier(0);
+    C64_RD(0, 0)
 #pragma unroll
-    for (int dyi = 0; dyi < 3; ++dyi) {
-      const char* slot = lX + ((h + dyi) & 3) * X_SLOT;
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) {
+        C64_RD((t + 1) & 1, t + 1)
+        DTP_LGKM_WAIT4(4, xf[t & 1][0], xf[t & 1][1], xf[t & 1][2], xf[t & 1][3]);
+      } else {
+        DTP_LGKM_WAIT4(0, xf[t & 1][0], xf[t & 1][1], xf[t & 1][2], xf[t & 1][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int dxi = 0; dxi < 3; ++dxi) {
+      for (int k = 0; k < 4; ++k)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], __builtin_bit_cast(bf16x8_t, xf[t & 1][k]), acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef C64_RD
+    {
+      // bias: register 4q + e holds cout 8q + 4hb + e -> one 16-byte LDS read per q
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = (2 * k + hb) ^ xsw[dxi];
-          const bf16x8_t xf = *(const bf16x8_t*)(slot + xbase[dxi] + (c << 4));
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[dyi * 3 + dxi][k], xf, acc, 0, 0, 0);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const f32x4_t b4 = *(const f32x4_t*)(lBias + wave * 32 + 8 * q + 4 * hb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q * 4 + e] += b4[e];
       }
     }
     if (!POOL && p.acc_src) {
@@ -327,11 +349,11 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
   }
   const long grid2 = units * p.RC;
   if (O == 64) {
-    constexpr int lds = 4 * 40 * 128 + 2 * 2048 + 128 * 32;
+    constexpr int lds = 4 * 40 * 128 + 2 * 2048 + 128 * 32 + 64 * 4;
     if (codes) hipLaunchKernelGGL((conv_c64_kernel<64, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
     else hipLaunchKernelGGL((conv_c64_kernel<64, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
   } else {
-    constexpr int lds = 4 * 40 * 128 + 4 * 2048 + 256 * 32;
+    constexpr int lds = 4 * 40 * 128 + 4 * 2048 + 256 * 32 + 128 * 4;
     if (codes) hipLaunchKernelGGL((conv_c64_kernel<128, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((conv_c64_kernel<128, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
   }

@@ -47,6 +47,44 @@ DTP_DEVINL void sync_lds_dma() {
   __syncthreads();
 }
 
+// Transposing LDS reads from inline asm.  hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 that follows an LDS-DMA (the builtin has no memory operand, so
+// the waitcnt pass assumes it may read what the DMA still writes): a prefetch issued before the
+// fragment reads was always drained before the first MFMA.  These forms are invisible to that pass;
+// the caller counts lgkmcnt itself and waits with DTP_LGKM_WAIT*, which names the registers it
+// releases "+v" so that no use (or compiler copy) of them can move above the wait.
+#define DTP_TR1(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+// one bf16x8 MFMA fragment = two reads (k rows +0..3 and +4..7 of an 8-row group, RB_ bytes per row)
+#define DTP_TR2(lo, hi, addr, IMM, RB_)                                                        \
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"    \
+               : "=&v"(lo), "=&v"(hi)                                                          \
+               : "v"(addr), "n"(IMM), "n"((IMM) + 4 * (RB_)))
+#define DTP_LGKM_WAIT2(N, a, b) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N))
+#define DTP_LGKM_WAIT4(N, a, b, c, d) \
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N))
+// 16-byte LDS read the compiler does not track (same contract as DTP_TR1): hipcc waits lgkmcnt(0)
+// where a counted wait would do once reads are software-pipelined past an MFMA group
+#define DTP_DSR128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+DTP_DEVINL bf16x8_t frag_of(u32x2_t lo, u32x2_t hi) {
+  return __builtin_bit_cast(bf16x8_t, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+}
+DTP_DEVINL unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// Buffer descriptor over [base, base + bytes): loads / stores / LDS-DMA through it are range-checked
+// per lane by the hardware — an out-of-range lane loads zeros (LDS-DMA: writes zeros to its LDS slot,
+// measured in bench/micro/lds_probe.hip) and its store is dropped.  Tails need no branches.
+#define DTP_OOB_OFF 0x80000000u
+DTP_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const void* base, long bytes) {
+  const unsigned n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFl ? 0x7FFFFFFFu : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)n, 0x00020000);
+}
+DTP_DEVINL void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0,
+                                           0, 0);
+}
+
 // Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
 // XCD a contiguous run of tile ids for L2 reuse (cdna_hip_programming.md T1). Speed only.
 DTP_DEVINL int xcd_remap(int bid, int nwg) {

@@ -42,27 +42,11 @@ struct Wgrad2Params {
   int nwrap;          // how often (h >= H) can hold after advancing a pixel row by one K-step
 };
 
-#define DTP_OOB_OFF 0x80000000u
-DTP_DEVINL void glds16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, void* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0,
-                                           0, 0);
-}
-DTP_DEVINL __amdgpu_buffer_rsrc_t make_rsrc(const char* base, long bytes) {
-  const unsigned n = bytes <= 0 ? 0u : (bytes > 0x7FFFFFFFl ? 0x7FFFFFFFu : (unsigned)bytes);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)n, 0x00020000);
-}
-
 template <int RB>
 DTP_DEVINL int s_of2(int k) {   // swizzle (in 16-B chunks) of LDS row k for an image with RB-byte rows (= wgrad.hip s_of)
   if (RB >= 256) return ((k & 3) | (((k >> 3) & 1) << 2)) << 1;
   return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1;
 }
-
-// one transposed fragment = two ds_read_b64_tr_b16 (k rows +0..3 and +4..7 of an 8-row group)
-#define TR2(lo, hi, addr, IMM, RB_)                                                             \
-  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"     \
-               : "=&v"(lo), "=&v"(hi)                                                           \
-               : "v"(addr), "n"(IMM), "n"((IMM) + 4 * (RB_)))
 
 template <int BM, int BN, int WGM, int WGN, bool TAPS9>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt2_kernel(const Wgrad2Params p) {
@@ -177,7 +161,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt2_kernel(const Wgrad2P
   const int sa = s_of2<RBA>(krow), sb = s_of2<RBB>(krow);
   const int a_cw = (wm * WM) >> 3, b_cw = (wn * WN) >> 3;
   const int sub = (pp >> 1), half8 = (pp & 1) * 8;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = lds_addr(smem);
   unsigned a_ad[MI], b_ad[NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) a_ad[i] = lds0 + krow * RBA + ((((a_cw + 2 * i) ^ sa) + sub) << 4) + half8;
@@ -195,22 +179,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt2_kernel(const Wgrad2P
 
 #define RD_A(slot, ks, mh)                                                                     \
   _Pragma("unroll") for (int i = 0; i < MIH; ++i)                                              \
-      TR2(xl[slot][i], xh[slot][i], a_ad[(mh) * MIH + i], (ks) * 32 * RBA, RBA);
+      DTP_TR2(xl[slot][i], xh[slot][i], a_ad[(mh) * MIH + i], (ks) * 32 * RBA, RBA);
 #define RD_B(slot, ks)                                                                         \
-  _Pragma("unroll") for (int j = 0; j < NI; ++j) TR2(wl[slot][j], wh[slot][j], b_ad[j], (ks) * 32 * RBB, RBB);
+  _Pragma("unroll") for (int j = 0; j < NI; ++j) DTP_TR2(wl[slot][j], wh[slot][j], b_ad[j], (ks) * 32 * RBB, RBB);
 // wait until at most N LDS reads of this wave are outstanding; naming the consumed registers "+v"
 // keeps every use (and any compiler copy) of them behind the wait
 #define WAIT_A(N, slot)                                                                        \
   _Pragma("unroll") for (int i = 0; i < MIH; ++i)                                              \
-      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(xl[slot][i]), "+v"(xh[slot][i]) : "n"(N));
+      DTP_LGKM_WAIT2(N, xl[slot][i], xh[slot][i]);
 #define WAIT_B(N, slot)                                                                        \
   _Pragma("unroll") for (int j = 0; j < NI; ++j)                                               \
-      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wl[slot][j]), "+v"(wh[slot][j]) : "n"(N));
+      DTP_LGKM_WAIT2(N, wl[slot][j], wh[slot][j]);
 #define MMA(aslot, bslot, mh)                                                                  \
   _Pragma("unroll") for (int i = 0; i < MIH; ++i) {                                            \
-    const bf16x8_t xa_ = __builtin_bit_cast(bf16x8_t, (u32x4_t){xl[aslot][i][0], xl[aslot][i][1], xh[aslot][i][0], xh[aslot][i][1]}); \
+    const bf16x8_t xa_ = frag_of(xl[aslot][i], xh[aslot][i]);                                  \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                           \
-      const bf16x8_t wb_ = __builtin_bit_cast(bf16x8_t, (u32x4_t){wl[bslot][j][0], wl[bslot][j][1], wh[bslot][j][0], wh[bslot][j][1]}); \
+      const bf16x8_t wb_ = frag_of(wl[bslot][j], wh[bslot][j]);                                \
       acc[(mh) * MIH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb_, xa_, acc[(mh) * MIH + i][j], 0, 0, 0); \
     }                                                                                          \
   }

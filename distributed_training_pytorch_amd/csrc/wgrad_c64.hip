@@ -73,6 +73,13 @@ __global__ __launch_bounds__(COUT * 4) void wgrad_c64_kernel(const WgC64Params p
       xo[d][r] = pos * 128 + ((((2 * wn) ^ sw128(pos)) + sub) << 4) + half8;
     }
 
+  // LDS byte addresses for the asm transposed reads (see dtp_common.h: the builtin form made hipcc
+  // drain the LDS-DMA of the next row before the first fragment read of this one)
+  const unsigned lds0 = lds_addr(smem);
+  unsigned a_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_off[i] = lds0 + 4 * X_SLOT + krow * RBA + ((((a_cw + 2 * i) ^ sa) + sub) << 4) + half8;
+
   f32x4_t acc[4][9];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -130,29 +137,38 @@ __global__ __launch_bounds__(COUT * 4) void wgrad_c64_kernel(const WgC64Params p
         stage_x(h + 2);
         stage_dy(h + 1);
       }
-      const char* bD = lD + (h & 1) * DY_BYTES;
-      bf16x8_t af[4];
+      // dY fragments (8 reads) + the first tap's X fragment (2 reads); then per tap: issue the
+      // next tap's two reads, wait for this tap's, 4 MFMAs.  The DMA issued above stays in flight.
+      const unsigned dsel = (h & 1) * DY_BYTES;
+      u32x2_t al[4], ah[4], bl[2], bh[2];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ch = ((a_cw + 2 * i) ^ sa) + sub;
-        const char* a0 = bD + krow * RBA + (ch << 4) + half8;
-        s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0));
-        s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(a0 + 4 * RBA));
-        af[i] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      for (int i = 0; i < 4; ++i) DTP_TR2(al[i], ah[i], a_off[i] + dsel, 0, RBA);
+      {
+        const unsigned slot = lds0 + ((h + 0) & 3) * X_SLOT;
+        DTP_TR1(bl[0], slot + xo[0][0]);
+        DTP_TR1(bh[0], slot + xo[0][1]);
       }
 #pragma unroll
-      for (int dyi = 0; dyi < 3; ++dyi) {
-        const char* slot = lX + ((h + dyi) & 3) * X_SLOT;     // row h + dyi - 1 lives in slot (row+1)&3
-#pragma unroll
-        for (int dxi = 0; dxi < 3; ++dxi) {
-          s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slot + xo[dxi][0]));
-          s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(slot + xo[dxi][1]));
-          const bf16x8_t bf = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[i][dyi * 3 + dxi] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][dyi * 3 + dxi], 0, 0, 0);
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) {
+          const int dyi = (t + 1) / 3, dxi = (t + 1) % 3;
+          const unsigned slot = lds0 + ((h + dyi) & 3) * X_SLOT;     // row h + dyi - 1 lives in slot (row+1)&3
+          DTP_TR1(bl[(t + 1) & 1], slot + xo[dxi][0]);
+          DTP_TR1(bh[(t + 1) & 1], slot + xo[dxi][1]);
         }
+        if (t == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) DTP_LGKM_WAIT2(2, al[i], ah[i]);
+        }
+        if (t + 1 < 9) DTP_LGKM_WAIT2(2, bl[t & 1], bh[t & 1]);
+        else DTP_LGKM_WAIT2(0, bl[t & 1], bh[t & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8_t bf = frag_of(bl[t & 1], bh[t & 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, frag_of(al[i], ah[i]), acc[i][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
