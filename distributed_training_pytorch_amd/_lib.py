@@ -53,6 +53,12 @@ _SIGS = {
     "dtp_relu_mask": [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p],
     "dtp_softmax_xent": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_int, c_float, c_float, c_void_p],
+    "dtp_bn_fwd_train": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
+                         c_float, c_float, c_int, c_void_p],
+    "dtp_bn_fwd_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float,
+                        c_int, c_void_p],
+    "dtp_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
+                   c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "dtp_sgd_flat": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                      c_float, c_float, c_int, c_int, c_void_p],
     "dtp_adamw_flat": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,

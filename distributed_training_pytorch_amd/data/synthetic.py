@@ -23,14 +23,17 @@ def _prototypes(num_classes, channels, height, width, seed):
 
 class SyntheticImageDataset(Dataset):
     def __init__(self, num_samples, num_classes=3, height=224, width=224, channels=3, seed=0,
-                 signal=1.0, uint8=False):
+                 signal=1.0, uint8=False, proto_seed=0):
         self.num_samples = int(num_samples)
         self.num_classes = int(num_classes)
         self.shape = (channels, height, width)
         self.seed = int(seed)
         self.signal = float(signal)
         self.uint8 = bool(uint8)
-        self.protos = _prototypes(num_classes, channels, height, width, seed)
+        # the class prototypes define the TASK and are shared by every split (train / val / test
+        # differ in ``seed`` = their noise and sample order only); with per-split prototypes a model
+        # trained on one split could never beat chance on another
+        self.protos = _prototypes(num_classes, channels, height, width, proto_seed)
 
     def __len__(self):
         return self.num_samples

@@ -19,24 +19,12 @@ import os
 import torch
 import torch.nn as nn
 
-from ..ops.layers import (AvgPoolFlatten, Conv3x3, ConvFirst, Linear, MaxPool2x2, ReLUMarker,
-                          conv_relu_pool)
+from ..ops.layers import (AvgPoolFlatten, BatchNormReLU, Conv3x3, ConvFirst, Linear, MaxPool2x2, ReLUMarker,
+                          conv_bn_relu_folded, conv_relu_pool)
 from .fused_model import FusedModel
 
 
 SELF_MASK = os.environ.get("DTP_CONV1_SELF_MASK", "1") == "1"     # A/B switch (see ConvBlock)
-
-
-class BatchNormNHWC(nn.BatchNorm2d):
-    """BatchNorm over the channel axis of the internal NHWC bf16 layout (VGG16-BN variant).
-    Stays on PyTorch-ROCm's batch-norm kernels (explicit decision): the tensor is
-    handed over as a channels_last NCHW *view*, no copy."""
-
-    def forward(self, x):
-        if not x.is_cuda:
-            return super().forward(x)
-        y = super().forward(x.permute(0, 3, 1, 2))
-        return y.permute(0, 2, 3, 1).contiguous()
 
 
 class ConvBlock(nn.Module):
@@ -61,10 +49,13 @@ class ConvBlock(nn.Module):
                                # 1-bit (y > 0) masks for the next conv's data gradient; a block's last
                                # conv feeds the pool, whose codes already carry the sign
                                emit_relu_bits=fused_relu and i < num_layers - 1)
+            conv.bn_follows = bool(batch_norm)       # its bias gradient is identically zero in training
             layers.append(conv)
             if batch_norm:
-                layers.append(BatchNormNHWC(out_channels))
-            layers.append(ReLUMarker(active=batch_norm))
+                # conv -> BatchNorm -> ReLU: normalisation and ReLU are one hand-written kernel pair
+                # (csrc/bn.hip); the marker keeps the Sequential indices of a torch VGG16-BN
+                layers.append(BatchNormReLU(out_channels))
+            layers.append(ReLUMarker())
         layers.append(MaxPool2x2(relu_mask=not batch_norm))
         self.conv = nn.Sequential(*layers)
         self.batch_norm = batch_norm
@@ -81,6 +72,20 @@ class ConvBlock(nn.Module):
                 return y
             for m in mods[-3:]:
                 x = m(x)
+            return x
+        if x.is_cuda and self.batch_norm and not self.training and not torch.is_grad_enabled():
+            # inference: each conv + BatchNorm + ReLU triple is ONE convolution with folded weights
+            mods = list(self.conv)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, (Conv3x3, ConvFirst)) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNormReLU):
+                    y = conv_bn_relu_folded(m, mods[i + 1], x)
+                    if y is not None:
+                        x, i = y, i + 2
+                        continue
+                x = m(x)
+                i += 1
             return x
         return self.conv(x)
 

@@ -624,6 +624,76 @@ def conv1_wgrad(x, dy, out_w, out_b, beta_w=0.0, beta_b=0.0, scale=1.0, mean=Non
     check(rc, "conv1_wgrad")
 
 
+def _bn_check(y, C, *vecs):
+    _need(y, BF16, "y")
+    if y.shape[-1] != C or C < 64 or C > 512 or C & (C - 1):
+        raise ValueError("batch norm: channel count must be a power of two in [64, 512], got %s" % (tuple(y.shape),))
+    for v in vecs:
+        if v is None:
+            continue
+        if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != C:
+            raise ValueError("batch norm: per-channel vectors must be contiguous CUDA f32 [C]")
+
+
+def bn_fwd_train(y, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, relu=True):
+    """z = (relu) batch_norm(y) over the rows of NHWC bf16 y [..., C] with the batch statistics;
+    running_mean / running_var are updated in place (unbiased variance, like torch).  Returns
+    (z, stats) with stats = [mean | rstd | scale | shift] (f32 [4*C]) for the backward pass."""
+    C = y.shape[-1]
+    _bn_check(y, C, gamma, beta, running_mean, running_var)
+    M = y.numel() // C
+    z = torch.empty_like(y)
+    stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
+    part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    check(_lib.hip().dtp_bn_fwd_train(ptr(y), ptr(z), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                      ptr(stats), ptr(part), M, C, float(eps), float(momentum), int(relu), stream()),
+          "bn_fwd_train")
+    return z, stats
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps=1e-5):
+    """(scale, shift) of eval-mode batch norm: y*scale + shift (for folding into a convolution)."""
+    C = gamma.numel()
+    co = torch.empty(2 * C, dtype=torch.float32, device=gamma.device)
+    for v in (gamma, beta, running_mean, running_var):
+        if not v.is_cuda or v.dtype != torch.float32 or not v.is_contiguous() or v.numel() != C:
+            raise ValueError("bn_eval_coeffs: contiguous CUDA f32 [C] vectors")
+    check(_lib.hip().dtp_bn_fwd_eval(None, None, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(co),
+                                     1, C, float(eps), 0, stream()),
+          "bn_eval_coeffs")
+    return co[:C], co[C:]
+
+
+def bn_fwd_eval(y, gamma, beta, running_mean, running_var, eps=1e-5, relu=True):
+    C = y.shape[-1]
+    _bn_check(y, C, gamma, beta, running_mean, running_var)
+    z = torch.empty_like(y)
+    co = torch.empty(2 * C, dtype=torch.float32, device=y.device)
+    check(_lib.hip().dtp_bn_fwd_eval(ptr(y), ptr(z), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), ptr(co),
+                                     y.numel() // C, C, float(eps), int(relu), stream()), "bn_fwd_eval")
+    return z
+
+
+def bn_bwd(y, dz, gamma, stats, dgamma, dbeta, beta_g=0.0, beta_b=0.0, relu=True):
+    """dy of (relu) batch_norm given the forward's input y and ``stats``; dgamma / dbeta ([C], f32
+    or bf16, same dtype) are written (beta_* = 0) or accumulated into (beta_* = 1)."""
+    C = y.shape[-1]
+    _bn_check(y, C, gamma)
+    _need(dz, BF16, "dz")
+    if dz.numel() != y.numel() or stats.numel() != 4 * C or stats.dtype != torch.float32:
+        raise ValueError("bn_bwd: bad shapes")
+    if dgamma.dtype != dbeta.dtype or dgamma.dtype not in (torch.float32, BF16) or dgamma.numel() != C \
+            or dbeta.numel() != C or not dgamma.is_contiguous() or not dbeta.is_contiguous():
+        raise ValueError("bn_bwd: dgamma / dbeta must be contiguous [C] of one dtype (f32 / bf16)")
+    dy = torch.empty_like(y)
+    part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    work = workspace.get("bn_work", 2 * 512, torch.float32, y.device)
+    check(_lib.hip().dtp_bn_bwd(ptr(y), ptr(dz), ptr(dy), ptr(gamma), ptr(stats), ptr(dgamma), ptr(dbeta),
+                                int(dgamma.dtype == torch.float32), float(beta_g), float(beta_b), ptr(part), ptr(work),
+                                y.numel() // C, C, int(relu), stream()), "bn_bwd")
+    return dy
+
+
 def cast_f32_bf16(src, dst):
     _need(src, torch.float32, "src")
     _need(dst, BF16, "dst")

@@ -74,6 +74,20 @@ def _side_stream(device):
     return s
 
 
+def _bias_grad(layer, arena, dy2d, bias):
+    """Bias gradient of a convolution = column sums of its dY.  When a training-mode BatchNorm
+    follows the convolution, dY comes out of the BatchNorm backward and its column sums are zero by
+    construction (sum_rows dY = g * (S1 - M*c1 - c2 * sum_rows xhat) with c1 = S1/M and
+    sum_rows xhat = 0): the bias cannot influence a batch-normalised output, so the 1x read of dY by
+    the column-sum kernel is skipped and an exact zero is written (or nothing, when accumulating)."""
+    beta = arena.grad_beta(bias)
+    if getattr(layer, "bn_follows", False) and layer.training:
+        if beta == 0.0:
+            arena.grad(bias).zero_()
+        return
+    K.bias_grad(dy2d, arena.grad(bias), beta=beta)
+
+
 def _arena_of(layer):
     a = getattr(layer, "_arena", None)
     if a is None:
@@ -152,7 +166,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         if ctx.has_bias:
-            K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            _bias_grad(layer, arena, dy.view(-1, Co), bias)
         dx = None
         if ctx.needs_input_grad[0]:
             Ci = weight.shape[1]
@@ -321,7 +335,7 @@ class _ConvFirstFn(torch.autograd.Function):
                 dst.copy_(g)
             else:
                 dst.add_(g)
-            K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+            _bias_grad(layer, arena, dy.view(-1, Co), bias)
         arena.notify_grad_ready(bias)
         arena.notify_grad_ready(weight)
         return None, None, None, None
@@ -542,6 +556,103 @@ class Linear(_LinearDerived, FusedLayer):
             return _LinearFn.apply(x, self.weight, self.bias, self, p, self._seed_salt, self.device_seed)
         seed = (torch.initial_seed() * 1000003 + next(_seed_counter)) & (2 ** 63 - 1) if p > 0 else 0
         return _LinearFn.apply(x, self.weight, self.bias, self, p, seed)
+
+
+# =============================================================================== batch norm (+ ReLU)
+class _BatchNormReLUFn(torch.autograd.Function):
+    """Training-mode BatchNorm + ReLU on NHWC bf16 (csrc/bn.hip): batch statistics, running-stat
+    update, normalise + affine + ReLU in the forward; the backward recomputes the ReLU mask from
+    the saved convolution output, reduces d(gamma) / d(beta) straight into the gradient arena and
+    emits the convolution's incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, layer):
+        arena = _arena_of(layer)
+        y = y.contiguous()
+        z, stats = K.bn_fwd_train(y, arena.flat_slice(arena.flat_master, weight), arena.flat_slice(arena.flat_master, bias),
+                                  layer.running_mean, layer.running_var, layer.eps, layer.momentum, layer.relu)
+        ctx.layer = layer
+        ctx.save_for_backward(y, stats, weight, bias)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        y, stats, weight, bias = ctx.saved_tensors
+        dy = K.bn_bwd(y, dz.contiguous(), arena.flat_slice(arena.flat_master, weight), stats, arena.grad(weight),
+                      arena.grad(bias), arena.grad_beta(weight), arena.grad_beta(bias), relu=layer.relu)
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        return dy, None, None, None
+
+
+class BatchNormReLU(FusedLayer):
+    """BatchNorm2d over the channel axis of the internal NHWC bf16 layout with the following ReLU
+    fused (VGG16-BN, BASELINE.json config 5).  Parameter and buffer names are ``nn.BatchNorm2d``'s
+    (``weight, bias, running_mean, running_var, num_batches_tracked``), so checkpoints interchange
+    with a stock ``torch.nn`` VGG16-BN.  GPU: hand-written kernels in training AND eval (eval-mode
+    normalisation is folded into the preceding convolution by ``ConvBlock`` when no gradient is
+    needed); CPU: ``F.batch_norm`` reference."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, relu=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.relu = num_features, float(eps), float(momentum), bool(relu)
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def eval_coeffs(self):
+        """(scale, shift) of the eval-mode affine map, from the fp32 master parameters."""
+        arena = _arena_of(self)
+        return K.bn_eval_coeffs(arena.flat_slice(arena.flat_master, self.weight),
+                                arena.flat_slice(arena.flat_master, self.bias), self.running_mean, self.running_var,
+                                self.eps)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training,
+                             self.momentum, self.eps)
+            if self.training:
+                self.num_batches_tracked += 1
+            return F.relu(y) if self.relu else y
+        if self.training:
+            self.num_batches_tracked += 1
+            return _BatchNormReLUFn.apply(x, self.weight, self.bias, self)
+        arena = _arena_of(self)
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("eval-mode BatchNormReLU on the GPU is inference-only (no autograd)")
+        return K.bn_fwd_eval(x.contiguous(), arena.flat_slice(arena.flat_master, self.weight),
+                             arena.flat_slice(arena.flat_master, self.bias), self.running_mean, self.running_var,
+                             self.eps, self.relu)
+
+    def extra_repr(self):
+        return "%d, eps=%g, momentum=%g, relu=%s" % (self.num_features, self.eps, self.momentum, self.relu)
+
+
+def conv_bn_relu_folded(conv, bn, x):
+    """Inference: ``relu(bn(conv(x)))`` as ONE convolution kernel — the eval-mode scale is folded
+    into the bf16 filter copy and scale/shift into the bias (cached until the weights or the
+    running statistics change), so BatchNorm costs nothing at evaluation time."""
+    arena = _arena_of(conv)
+    key = (arena.lp_epoch, bn.running_mean._version, bn.running_var._version)
+    cached = conv.__dict__.get("_bnfold")
+    if cached is None or cached[0] != key:
+        scale, shift = bn.eval_coeffs()
+        w = arena.lp(conv.weight)
+        wf = (w.float() * scale.view(-1, 1)).to(BF16).contiguous()
+        bf = (conv.bias.detach().float() * scale + shift).contiguous()
+        cached = (key, wf, bf)
+        conv.__dict__["_bnfold"] = cached
+    _, wf, bf = cached
+    if isinstance(conv, ConvFirst):
+        x = x.contiguous()
+        if x.shape[1] != 3:
+            return None
+        return K.conv1_fprop(x, wf, bf, bn.relu, conv.in_scale, conv.in_mean, conv.in_inv_std)
+    return K.conv3x3_fprop(x, wf, bf, relu=bn.relu)
 
 
 class ReLUMarker(nn.Module):

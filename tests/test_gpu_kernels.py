@@ -715,3 +715,54 @@ def test_linear_dgrad_on_native_weight_layout(shape):
     _close(dx, ref, 2e-2, 2e-2, "tt dgrad %s" % (shape,))
     via_wt = k.linear_dgrad(dy, k.linear_weight_transpose(w))
     _close(dx, via_wt.float(), 2e-2, 1e-2, "tt vs nt dgrad %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64), (3, 9, 7, 128), (2, 28, 28, 256), (5, 7, 7, 512), (64, 56, 56, 64)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_relu_fwd_bwd_against_torch(shape, relu):
+    """csrc/bn.hip against F.batch_norm (+ relu) in fp32 on the same bf16-rounded values: output,
+    running statistics (momentum, unbiased variance), dY, d(gamma), d(beta); f32 and bf16 gradient
+    outputs with accumulation; eval mode from the running statistics."""
+    k = _k()
+    N, H, W, C = shape
+    torch.manual_seed(21)
+    y = (_rand(N, H, W, C).float() * (1.0 + torch.arange(C, device="cuda") % 5) + 0.3 * (torch.arange(C, device="cuda") % 7 - 3)).to(BF16)
+    dz = _rand(N, H, W, C, scale=0.1)
+    gamma = (1.0 + 0.2 * torch.randn(C, device="cuda")).contiguous()
+    beta = (0.3 * torch.randn(C, device="cuda")).contiguous()
+    rm, rv = 0.1 * torch.randn(C, device="cuda"), 0.5 + torch.rand(C, device="cuda")
+    rm_k, rv_k = rm.clone(), rv.clone()
+    z, stats = k.bn_fwd_train(y, gamma, beta, rm_k, rv_k, eps=1e-5, momentum=0.1, relu=relu)
+    # fp32 reference on the same inputs
+    yr = y.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    g_r, b_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    zr = F.batch_norm(yr, rm_r, rv_r, g_r, b_r, True, 0.1, 1e-5)
+    if relu:
+        zr = zr.relu()
+    _close(z, zr.permute(0, 2, 3, 1), 1e-2, 1e-2, "bn fwd %s" % (shape,))
+    assert torch.allclose(rm_k, rm_r, atol=1e-4, rtol=1e-4) and torch.allclose(rv_k, rv_r, atol=1e-4, rtol=1e-3)
+    zr.backward(dz.float().permute(0, 3, 1, 2))
+    # the kernel's ReLU mask comes from ITS forward value; at |z| ~ 0 the fp32 reference may differ by
+    # one element's sign: compare against the reference masked with the kernel's own output
+    for dt in (torch.float32, BF16):
+        dg = torch.full((C,), 0.25, device="cuda", dtype=dt)
+        db = torch.full((C,), -0.5, device="cuda", dtype=dt)
+        dy = k.bn_bwd(y, dz, gamma, stats, dg, db, beta_g=1.0, beta_b=1.0, relu=relu)
+        M = N * H * W
+        tol_g = 3e-2 * (g_r.grad.abs().max().item() + 1.0)
+        assert (dg.float() - (g_r.grad + 0.25)).abs().max().item() < tol_g, "dgamma %s %s" % (shape, dt)
+        assert (db.float() - (b_r.grad - 0.5)).abs().max().item() < 3e-2 * (b_r.grad.abs().max().item() + 1.0), "dbeta"
+        _close(dy, yr.grad.permute(0, 2, 3, 1), 3e-2, 3e-2 * yr.grad.abs().max().item() + 1e-5, "bn dy %s" % (shape,))
+    # eval mode: running statistics
+    ze = k.bn_fwd_eval(y, gamma, beta, rm_k, rv_k, 1e-5, relu)
+    zer = F.batch_norm(y.float().permute(0, 3, 1, 2), rm_k, rv_k, gamma, beta, False, 0.1, 1e-5)
+    if relu:
+        zer = zer.relu()
+    _close(ze, zer.permute(0, 2, 3, 1), 1e-2, 1e-2, "bn eval %s" % (shape,))
+    sc, sh = k.bn_eval_coeffs(gamma, beta, rm_k, rv_k, 1e-5)
+    assert torch.allclose(sc, gamma / torch.sqrt(rv_k + 1e-5), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sh, beta - rm_k * sc, rtol=1e-5, atol=1e-5)
+    # determinism (two-level reductions, no atomics)
+    z2, stats2 = k.bn_fwd_train(y, gamma, beta, rm.clone(), rv.clone(), relu=relu)
+    assert torch.equal(z, z2) and torch.equal(stats, stats2)

@@ -421,9 +421,10 @@ def test_hip_graph_step_matches_eager_and_redraws_dropout():
 
 @pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
 def test_vgg16_bn_trains_on_gpu(grad_dtype):
-    """VGG16-BN (BASELINE config 5 model): fused convs/linears + PyTorch-ROCm batch-norm on the NHWC
-    view; BN affine gradients come from autograd and must reach the flat arena in both gradient
-    dtypes; eval-mode forward agrees with the fp32 CPU path of the same weights."""
+    """VGG16-BN (BASELINE config 5 model): fused convs/linears + the hand-written BatchNorm+ReLU
+    kernels (csrc/bn.hip); BN affine gradients are written into the flat arena by the kernels in
+    both gradient dtypes; the eval-mode forward (conv + BN + ReLU folded into one convolution)
+    agrees with the fp32 CPU path of the same weights."""
     from distributed_training_pytorch_amd.models.vgg16 import vgg16_bn
     from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
     from distributed_training_pytorch_amd.ops.optim import FusedSGD
@@ -458,6 +459,47 @@ def test_vgg16_bn_trains_on_gpu(grad_dtype):
     assert not torch.equal(conv_w.detach(), cw0)
     assert min(losses[10:]) < 0.5 * losses[0], losses
     assert float(gpu.backbone[0].conv[1].num_batches_tracked) == 30
+    # the trained model: folded eval forward == unfolded eval forward == CPU reference of its weights
+    gpu.eval()
+    with torch.no_grad():
+        og = gpu(xg)
+    cpu2 = vgg16_bn(3, 3, dropout=0.0)
+    cpu2.load_state_dict(gpu.state_dict())
+    cpu2.eval()
+    with torch.no_grad():
+        oc2 = cpu2(x)
+    assert (og.cpu() - oc2).abs().max().item() < 0.05 * oc2.abs().max().item() + 5e-3
+    from distributed_training_pytorch_amd.ops.layers import BatchNormReLU
+    assert sum(isinstance(m, BatchNormReLU) for m in gpu.modules()) == 13
+    assert all(id(p) in gpu.param_arena.kernel_written for p in gpu.parameters())   # nothing left to autograd
+
+
+def test_config5_bn_fp8_train_snapshot_eval(tmp_path, capsys):
+    """BASELINE.json config 5 end to end on the GPU: train VGG16-BN with the fp8 (OCP e4m3)
+    classifier through the Trainer -> snapshot in the reference schema -> eval.py --batch-norm
+    --fp8-classifier reports top-1 on the synthetic test split (same class prototypes, fresh noise).
+    The batch-statistics model separates the classes after one epoch; the eval-mode model needs the
+    running statistics (momentum 0.1) to catch up with the fast-moving early weights — ~50 steps
+    (bench/debug_bn_eval.py) — hence 9 short epochs."""
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+    torch.manual_seed(5)
+    save = str(tmp_path / "runs")
+    tr = ExampleTrainer(train_path="synthetic:192", val_path="synthetic:48", labels=["a", "b", "c"], height=64, width=64,
+                        max_epoch=9, batch_size=32, pin_memory=True, have_validate=True,
+                        save_best_for=("accuracy", "geq"), save_period=1, save_folder=save, progress=False, lr=0.02,
+                        batch_norm=True, fp8_classifier=True, grad_dtype=torch.bfloat16)
+    tr.train()
+    assert tr.best_fitness["value"] is not None
+    import eval as eval_script
+    acc1, acck, n = eval_script.main(["--synthetic", "96", "--model", os.path.join(save, "weights", "last.pth"),
+                                      "--image-size", "64", "--labels", "a,b,c", "--batch-size", "32", "--batch-norm",
+                                      "--fp8-classifier", "--device", "cuda:0"])
+    assert n == 96 and acc1 > 0.9 and acck >= acc1, (acc1, acck)
+    assert "EVALUATION ACCURACY RESULTS: TOP-1=" in capsys.readouterr().out
 
 
 def test_fp8_classifier_forward_and_training():
@@ -544,3 +586,61 @@ def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport, world):
                        timeout=150)
     assert r.returncode == 0, r.stdout[-4000:]
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % i for i in range(world)]
+
+
+def test_pinned_ring_input_pipeline():
+    """The native pinned ring: (a) PinnedRingSource hands out exactly the bytes its producer wrote
+    (uint8 images + int64 labels), one step behind the copies it queues, without the host ever
+    waiting; (b) DevicePrefetcher stages UNPINNED loader batches through ring slots (no per-batch
+    pin_memory) and delivers bit-identical tensors, pinned ones bypass the ring; (c) a model trains
+    from the uint8 ring with the normalisation fused into conv1."""
+    from distributed_training_pytorch_amd.data.prefetch import DevicePrefetcher, PinnedRingSource
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    dev = torch.device("cuda", 0)
+    src = PinnedRingSource(8, 3, 32, 32, device=dev, seed=3, n_slots=3, threads=2)
+    seen = []
+    for k in range(7):
+        x, y = next(src)
+        torch.cuda.synchronize()
+        slot = k % 3
+        hx = src.ring.host_view(slot, 0, 8 * 3 * 32 * 32, torch.uint8, (8, 3, 32, 32))
+        hy = src.ring.host_view(slot, src.label_off, 8 * 8, torch.int64, (8,))
+        assert x.dtype == torch.uint8 and torch.equal(x.cpu(), hx) and torch.equal(y.cpu(), hy)
+        assert int(y.min()) >= 0 and int(y.max()) < 3
+        seen.append(x.cpu().clone())
+    assert not torch.equal(seen[0], seen[1]) and torch.equal(seen[0], seen[3])     # 3 distinct slots, cycled
+    assert 100 < float(seen[0].float().mean()) < 160                                # ~N(128, .) pixels
+    assert src.wait_ms_total() == 0.0 and src.ring.stats()["copies"] == 2 * 8
+    src.close()
+
+    # (b) generic loader path
+    data = [(torch.randn(4, 3, 16, 16), torch.arange(4) + 10 * i) for i in range(5)]
+    pf = DevicePrefetcher(data, dev)
+    got = list(pf)
+    assert pf.ring is not None and pf.ring.stats()["copies"] == 10                  # every tensor went through a slot
+    for (a, b), (ga, gb) in zip(data, got):
+        assert ga.is_cuda and torch.equal(ga.cpu(), a) and torch.equal(gb.cpu(), b)
+    pinned = [(a.pin_memory(), b.pin_memory()) for a, b in data]
+    pf2 = DevicePrefetcher(pinned, dev)
+    got2 = list(pf2)
+    assert pf2.ring is None and all(torch.equal(g[0].cpu(), d[0]) for g, d in zip(got2, data))
+
+    # (c) train from the uint8 ring
+    torch.manual_seed(0)
+    src = PinnedRingSource(16, 3, 32, 32, device=dev, seed=1, n_slots=4, threads=2)
+    model = VGG16(3, 3, True, dropout=0.0).to(dev)
+    model.set_input_normalization(*src.normalization)
+    opt = FusedSGD(model, lr=0.01, momentum=0.9)
+    crit = SoftmaxCrossEntropy()
+    losses = []
+    for _ in range(40):
+        x, y = next(src)
+        opt.zero_grad()
+        loss = crit(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and min(losses[20:]) < 0.7 * losses[0], losses
+    src.close()
