@@ -80,7 +80,7 @@ def build_runtime(verbose=False):
     out = os.path.join(LIBDIR, "libdtp_runtime.so")
     if _newer(objs, out):
         _run([HIPCC, "-shared", "-fPIC", "-o", out, *objs, "-L", os.path.join(ROCM, "lib"),
-              "-lrccl", "-lamdhip64", "-lpthread", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
+              "-lrccl", "-lamdhip64", "-lpthread", "-ldl", "-Wl,-rpath," + os.path.join(ROCM, "lib")])
     if verbose:
         print("built", out)
     return out

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,6 +61,37 @@ inline int fail(const char* what, int code) {
   } while (0)
 
 ncclDataType_t dtype_of(int kind) { return kind == 1 ? ncclBfloat16 : ncclFloat32; }
+
+// roctx ranges around every bucket launch ("allreduce-bucket-k" in
+// rocprofv3 --marker-trace).  Opt-in with DTP_ROCTX=1; the library is looked up at run time so that
+// this file links against nothing but HIP and RCCL.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* on = std::getenv("DTP_ROCTX");
+    if (!on || on[0] != '1') return;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+      if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (push && pop) return;
+        push = nullptr; pop = nullptr;
+      }
+    }
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct RoctxRange {
+  bool on;
+  RoctxRange(const char* what, int index, size_t bytes) : on(roctx().push != nullptr) {
+    if (!on) return;
+    char buf[96];
+    std::snprintf(buf, sizeof(buf), "dtp:%s bucket %d (%zu B)", what, index, bytes);
+    roctx().push(buf);
+  }
+  ~RoctxRange() { if (on) roctx().pop(); }
+};
 
 }  // namespace
 
@@ -270,6 +303,8 @@ struct DtpReducer {
 // one bucket: all-reduce, or reduce-scatter -> optimizer on the owned slice -> all-gather
 static int launch_bucket(DtpReducer* r, int bi, hipStream_t producer_stream) {
   DtpBucket& b = r->buckets[bi];
+  RoctxRange range(r->opt_kind == 0 ? "allreduce" : "reduce-scatter+opt+all-gather", bi,
+                   b.count * (b.dtype_kind == 1 ? 2 : 4));
   if (r->opt_kind == 0)
     return dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream);
   if (!r->pass_armed) return -30;      // begin_pass() must precede the first launch of a pass

@@ -8,8 +8,10 @@ pipeline = resize + normalise; returns ``(float32 CHW tensor, int label)``.
 cv2, albumentations and torchvision are not installable here, so decoding uses PIL
 and the augmentations are re-implemented on numpy/PIL: rot90, flips, box blur, median filter,
 brightness/contrast, gamma and JPEG re-compression are functional equivalents; CLAHE is
-approximated by PIL's global ``ImageOps.equalize`` blended 50/50 ("parity unpinned": no
-reference fixture pins augmentation outputs).  The file order is deterministic and identical on
+approximated by PIL's global ``ImageOps.equalize`` blended 50/50, and the blur / median kernel
+ranges (albumentations defaults: blur_limit 3..7) are sampled from {1, 2, 3} box radii and {3, 5}
+median sizes ("parity unpinned": albumentations / cv2 cannot be installed here and no reference
+fixture pins augmentation outputs, so the transforms are functional stand-ins, not bit matches).  The file order is deterministic and identical on
 every rank (quirk #3): shuffling is the sampler's job.
 """
 import io
@@ -43,6 +45,13 @@ class ExampleDataset(Dataset):
         # are then fused into the first convolution's ingest kernel (ConvFirst.set_input_normalization)
         self.uint8 = bool(uint8)
         self.data_list = self._load_data(data_path, self.labels)
+        # augmentation randomness is a function of (seed, epoch, sample index): every rank and every
+        # DataLoader worker draws an independent stream for each sample it serves (one shared
+        # random.Random(seed) gave all ranks and workers the SAME stream), the run is reproducible
+        # whatever the number of workers, and ``set_epoch`` (called by the Trainer next to the
+        # sampler's) changes the draws from epoch to epoch
+        self.seed = int(seed)
+        self.epoch = 0
         self.rng = random.Random(seed)
         self.mean = np.asarray(IMAGENET_MEAN, dtype=np.float32).reshape(3, 1, 1)
         self.std = np.asarray(IMAGENET_STD, dtype=np.float32).reshape(3, 1, 1)
@@ -61,6 +70,9 @@ class ExampleDataset(Dataset):
 
     def __len__(self):
         return len(self.data_list)
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
 
     # ---------------------------------------------------------------- augmentations
     def _augment(self, img):
@@ -100,6 +112,7 @@ class ExampleDataset(Dataset):
         path, lb = self.data_list[idx]
         img = Image.open(path).convert("RGB").resize((self.width, self.height), Image.BILINEAR)
         if self.phase == "train":
+            self.rng = random.Random((self.seed * 1000003 + self.epoch) * 2654435761 + idx)
             img = self._augment(img)
         if self.uint8:
             return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))), lb

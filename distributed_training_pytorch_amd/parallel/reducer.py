@@ -34,6 +34,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from ..utils.profiler import trace_range
 from . import comm
 
 
@@ -58,12 +59,20 @@ def plan_buckets(numels, elem_bytes, first_cap_bytes, cap_bytes, split_large_byt
         n = numels[idx]
         nbytes = n * elem_bytes
         if split_large_bytes and nbytes > split_large_bytes:
+            # what is pending and still small (e.g. the 8 KB linear1.bias in front of the 205 MB
+            # linear1.weight) rides in the split parameter's first chunk instead of becoming a
+            # collective of its own
+            carry = []
+            if cur and cur_bytes < first_cap_bytes:
+                carry, cur, cur_bytes = cur, [], 0
             close()
             chunk = max(1, split_large_bytes // elem_bytes)
             # reverse order inside the parameter too: high addresses first is arbitrary but fixed
             starts = list(range(0, n, chunk))
             for s in reversed(starts):
-                buckets.append([(idx, s, min(n, s + chunk))])
+                buckets.append(carry + [(idx, s, min(n, s + chunk))])
+                carry = []
+                cap = cap_bytes
             continue
         cur.append((idx, 0, n))
         cur_bytes += nbytes
@@ -414,6 +423,10 @@ class BucketedReducer(object):
             return
         b.launched = True
         buf = b.flat
+        with trace_range("bucket%d" % b.index):
+            self._launch_traced(b, buf)
+
+    def _launch_traced(self, b, buf):
         if self.sharded:
             self._begin_pass()
             b.work = self.transport.reduce_scatter(buf)

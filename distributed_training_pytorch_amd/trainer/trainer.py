@@ -306,6 +306,9 @@ class Trainer(object):
             sampler = getattr(self.train_dataloader, "sampler", None)
             if hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)
+            ds = getattr(self.train_dataloader, "dataset", None)
+            if hasattr(ds, "set_epoch"):         # per-epoch augmentation streams (data/image_folder.py)
+                ds.set_epoch(epoch)
             self.log(RULE)
             self.log("[GPU%d] Epoch %d/%d" % (self.world_rank, epoch + 1, self.max_epoch))
             sums, count = None, 0
@@ -435,7 +438,10 @@ class Trainer(object):
             return DeviceCachedLoader(dataset, batch_size, sampler, self.device)
         return DataLoader(dataset, batch_size=batch_size, pin_memory=pin_memory, shuffle=False,
                           sampler=sampler, collate_fn=collate_fn, num_workers=self.num_workers,
-                          persistent_workers=self.num_workers > 0, drop_last=False)
+                          # datasets with per-epoch state (set_epoch) get fresh workers every epoch so
+                          # that the workers' copies see it
+                          persistent_workers=self.num_workers > 0 and not hasattr(dataset, "set_epoch"),
+                          drop_last=False)
 
     # ------------------------------------------------------------------ hooks (T14)
     def build_train_dataset(self):

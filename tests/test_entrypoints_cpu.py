@@ -51,6 +51,15 @@ def test_image_folder_dataset(tmp_path):
     a, b = [t1[i][0] for i in range(6)], [t2[i][0] for i in range(6)]
     assert all(p.shape == (3, 24, 32) and torch.isfinite(p).all() for p in a)
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+    # ... a function of (seed, epoch, index) only: independent of call order (any rank / worker
+    # serving sample i draws the same stream; one shared RNG gave every rank identical streams and
+    # made the result depend on who asked first), different between samples and between epochs
+    t3 = ExampleDataset(str(tmp_path), labels, 24, 32, phase="train", seed=5)
+    assert torch.equal(t3[4][0], a[4]) and torch.equal(t3[1][0], a[1])         # reverse order, same pixels
+    t3.set_epoch(1)
+    assert any(not torch.equal(t3[i][0], a[i]) for i in range(6))
+    t4 = ExampleDataset(str(tmp_path), labels, 24, 32, phase="train", seed=6)
+    assert any(not torch.equal(t4[i][0], a[i]) for i in range(6))
     with pytest.raises(Exception):
         ExampleDataset(str(tmp_path / "missing"), labels, 24, 32, phase="val")[0]
 

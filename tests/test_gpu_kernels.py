@@ -766,3 +766,68 @@ def test_batchnorm_relu_fwd_bwd_against_torch(shape, relu):
     # determinism (two-level reductions, no atomics)
     z2, stats2 = k.bn_fwd_train(y, gamma, beta, rm.clone(), rv.clone(), relu=relu)
     assert torch.equal(z, z2) and torch.equal(stats, stats2)
+
+
+VGG_LAYERS = [  # every 3x3 layer of VGG16 after conv1_1: (Cin, Cout, H = W)
+    (64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 256, 56),
+    (256, 512, 28), (512, 512, 28), (512, 512, 28), (512, 512, 14), (512, 512, 14), (512, 512, 14),
+]
+
+
+@pytest.mark.parametrize("layer", sorted(set(VGG_LAYERS)))
+@pytest.mark.parametrize("N", [2, 3])
+def test_vgg_conv_shapes_through_the_production_pickers(layer, N):
+    """The REAL VGG16 layer shapes at 224x224 (not miniatures) through whatever tile configuration,
+    split factor and kernel family the production pickers choose for them — forward, masked data
+    gradient (1-bit masks) and weight gradient — against fp32 PyTorch on the same bf16 values."""
+    k = _k()
+    C, Co, HW = layer
+    torch.manual_seed(C + Co + HW + N)
+    x = _rand(N, HW, HW, C).relu_()                     # a ReLU output: about half the mask bits are 0
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    y, bits = k.conv3x3_fprop(x, w, b, relu=True, want_bits=True)
+    ref = _ref_conv(x, w, b, True)
+    _close(y, ref, 2e-2, 2e-2 * ref.abs().max().item(), "fprop %s" % (layer,))
+    if bits is not None:
+        got = (bits.view(-1, 1) >> torch.arange(8, device="cuda", dtype=torch.uint8)) & 1
+        assert torch.equal(got.view(-1).bool(), (y.view(-1) > 0))
+    dy = _rand(N, HW, HW, Co, scale=0.1)
+    wd = k.conv_weight_to_dgrad(w, Co, C)
+    xbits = ((x.view(-1, 8) > 0).to(torch.int32) * (2 ** torch.arange(8, device="cuda", dtype=torch.int32))).sum(1).to(torch.uint8)
+    dx = k.conv3x3_dgrad(dy, wd, mask_src=x, mask_bits=xbits)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().view(Co, 3, 3, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    out = F.conv2d(xr, wr, padding=1)
+    gx, gw = torch.autograd.grad(out, (xr, wr), dy.float().permute(0, 3, 1, 2))
+    refdx = (gx * (xr > 0)).permute(0, 2, 3, 1)
+    _close(dx, refdx, 2e-2, 2e-2 * refdx.abs().max().item(), "dgrad %s" % (layer,))
+    refgw = gw.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    for dt in (torch.float32, BF16):
+        g = torch.empty((Co, 9 * C), device="cuda", dtype=dt)
+        k.conv3x3_wgrad(dy, x, g)
+        _close(g, refgw, 2e-2, 2e-2 * refgw.abs().max().item(), "wgrad %s %s" % (layer, dt))
+
+
+@pytest.mark.parametrize("shape", [(2, 25088, 4096), (2, 4096, 4096), (2, 4096, 3), (1024, 25088, 4096)])
+def test_vgg_classifier_shapes_through_the_production_pickers(shape):
+    k = _k()
+    M, K, Nout = shape
+    torch.manual_seed(M + Nout)
+    x = _rand(M, K)
+    w = _rand(Nout, K, scale=K ** -0.5)
+    b = torch.randn(Nout, device="cuda")
+    y = k.linear_fwd(x, w, b, relu=False, out_fp32=Nout % 8 != 0)
+    ref = x.float() @ w.float().t() + b
+    _close(y, ref, 2e-2, 2e-2 * ref.abs().max().item(), "fc fwd %s" % (shape,))
+    ld = (Nout + 63) // 64 * 64
+    dy = torch.zeros(M, ld, device="cuda", dtype=BF16)
+    dy[:, :Nout] = _rand(M, Nout, scale=0.1)
+    gw = torch.empty(Nout, K, device="cuda")
+    k.linear_wgrad(dy, x, gw, n_valid=Nout)
+    refgw = dy.float()[:, :Nout].t() @ x.float()
+    _close(gw, refgw, 2e-2, 2e-2 * refgw.abs().max().item() + 1e-6, "fc wgrad %s" % (shape,))
+    wt = k.linear_weight_transpose(w)
+    dx = k.linear_dgrad(dy, wt)
+    refdx = dy.float()[:, :Nout] @ w.float()
+    _close(dx, refdx, 2e-2, 2e-2 * refdx.abs().max().item(), "fc dgrad %s" % (shape,))

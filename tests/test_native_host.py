@@ -17,7 +17,7 @@ def test_rccl_transport_host_logic_under_asan_ubsan(tmp_path):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
            "-fno-sanitize-recover=all", "-static-libasan", "-I", mock, "-I", os.path.join(ROOT, "tests", "native"),
            os.path.join(ROOT, "distributed_training_pytorch_amd", "csrc", "runtime", "rccl_transport.cpp"),
-           os.path.join(ROOT, "tests", "native", "transport_host_test.cpp"), "-o", exe, "-lpthread"]
+           os.path.join(ROOT, "tests", "native", "transport_host_test.cpp"), "-o", exe, "-lpthread", "-ldl"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-4000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
