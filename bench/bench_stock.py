@@ -13,14 +13,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-def make_vgg16(num_classes=3):
+def make_vgg16(num_classes=3, batch_norm=False):
     cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
     layers, c = [], 3
     for v in cfg:
         if v == "M":
             layers.append(nn.MaxPool2d(2, 2))
         else:
-            layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(True)]
+            layers += [nn.Conv2d(c, v, 3, padding=1)] + ([nn.BatchNorm2d(v)] if batch_norm else []) + [nn.ReLU(True)]
             c = v
     return nn.Sequential(*layers, nn.AdaptiveAvgPool2d((7, 7)), nn.Flatten(),
                          nn.Linear(25088, 4096), nn.ReLU(True), nn.Dropout(0.3),
@@ -34,11 +34,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch-norm", action="store_true", help="VGG16-BN (BASELINE.json config 5 comparison)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda")
     torch.manual_seed(0)
-    model = make_vgg16().to(dev)
+    model = make_vgg16(batch_norm=args.batch_norm).to(dev)
     if args.dtype == "bf16":
         model = model.to(memory_format=torch.channels_last)
     opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
@@ -76,7 +77,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    rec = dict(impl="stock-pytorch-rocm", dtype=args.dtype, batch=args.batch, steps=args.steps,
+    rec = dict(impl="stock-pytorch-rocm", dtype=args.dtype, batch=args.batch, steps=args.steps, batch_norm=args.batch_norm,
                ms_per_step=1e3 * dt / args.steps, images_per_sec=args.batch * args.steps / dt,
                loss=float(loss))
     print(json.dumps(rec), flush=True)

@@ -82,19 +82,38 @@ __global__ __launch_bounds__(BN_T) void bn_reduce_kernel(const u32x4_t* __restri
   }
 }
 
-// one thread per channel: fold the partial rows in a fixed order (double), derive the statistics
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M, float eps, float momentum,
+// Fold of the per-block partial rows, 16 channels per 256-thread block: thread (part, ch) sums rows
+// part, part + 16, ... in double, the 16 part sums are combined through LDS in a fixed order
+// (deterministic).  One thread per channel walking up to 1024 rows serially took 260-275 us per call
+// — 7 ms per VGG16-BN step of pure load latency.
+constexpr int BN_FC = 16;       // channels per finalize block
+DTP_DEVINL bool bn_fold(const float* __restrict__ partial, int nblk, int C, int c, int part, double (*red)[16][BN_FC],
+                        double& s, double& q) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int r = part; r < nblk; r += 16) {
+      a += (double)partial[((size_t)r * 2) * C + c];
+      b += (double)partial[((size_t)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][part][threadIdx.x & (BN_FC - 1)] = a;
+  red[1][part][threadIdx.x & (BN_FC - 1)] = b;
+  __syncthreads();
+  if (part != 0 || c >= C) return false;
+  s = 0.0; q = 0.0;
+  for (int k = 0; k < 16; ++k) { s += red[0][k][threadIdx.x]; q += red[1][k][threadIdx.x]; }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M, float eps, float momentum,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ running_mean,
                                    float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[((size_t)b * 2) * C + c];
-    q += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
+  __shared__ double red[2][16][BN_FC];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1));
+  double s, q;
+  if (!bn_fold(partial, nblk, C, c, threadIdx.x / BN_FC, red, s, q)) return;
   const double m = s / (double)M;
   double var = q / (double)M - m * m;
   if (var < 0.0) var = 0.0;
@@ -122,16 +141,13 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* __restrict_
   shift[c] = beta[c] - running_mean[c] * sc;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C, long M,
                                        void* __restrict__ dgamma, void* __restrict__ dbeta, int out_fp32,
                                        float beta_g, float beta_b, float* __restrict__ c1, float* __restrict__ c2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s += (double)partial[((size_t)b * 2) * C + c];
-    q += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
+  __shared__ double red[2][16][BN_FC];
+  const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1));
+  double s, q;
+  if (!bn_fold(partial, nblk, C, c, threadIdx.x / BN_FC, red, s, q)) return;
   c1[c] = (float)(s / (double)M);
   c2[c] = (float)(q / (double)M);
   if (out_fp32) {
@@ -213,7 +229,7 @@ extern "C" int dtp_bn_fwd_train(const void* y, void* z, const float* gamma, cons
   float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
   hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
                      nullptr, nullptr, partial, M, C, relu);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, nblk, C, M, eps, momentum, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, eps, momentum, gamma,
                      beta, mean, rstd, scale, shift, running_mean, running_var);
   const long nvec = M * (C >> 3);
   long g = (nvec + BN_T * 8 - 1) / (BN_T * 8);
@@ -250,7 +266,7 @@ extern "C" int dtp_bn_bwd(const void* y, const void* dz, void* dy, const float* 
   const float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
   hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, (const u32x4_t*)dz, scale,
                      shift, mean, rstd, partial, M, C, relu);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial, nblk, C, M, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, dgamma, dbeta,
                      grads_fp32, beta_g, beta_b, work, work + C);
   const long nvec = M * (C >> 3);
   long g = (nvec + BN_T * 8 - 1) / (BN_T * 8);

@@ -94,6 +94,12 @@ class DevicePrefetcher(object):
         return out, ev
 
     def __iter__(self):
+        if getattr(self.loader, "yields_device_batches", False):
+            # the loader runs its own copy pipeline (RingSyntheticLoader): pulling ahead of the
+            # consumer would recycle its device double buffer under the step that still reads it
+            for batch in self.loader:
+                yield batch
+            return
         it = iter(self.loader)
         queue = []
         try:
@@ -117,11 +123,15 @@ class DevicePrefetcher(object):
 
 class PinnedRingSource(object):
     """Endless iterator of (uint8 NCHW image batch, int64 labels) on the device, fed from the
-    pinned host ring: ``n_slots`` distinct synthetic batches are produced into page-locked memory by
-    native threads; every ``next()`` hands out the batch whose copy was queued one step earlier and
-    queues the following one — slot -> device double buffer on the copy stream, after the event of
-    the buffer's previous reader — so one H2D copy per step runs under the step's compute.
-    ``wait_ms_total()`` = time the host was blocked on the ring (0 when the pipeline keeps up)."""
+    pinned host ring.  Synthetic batches are produced into page-locked slots by native threads;
+    every ``next()`` hands out the batch whose copy was queued one step earlier and queues the
+    following one — slot -> device double buffer on the copy stream, after the event of the
+    buffer's previous reader — so one H2D copy per step runs under the step's compute.
+
+    ``refill=False``: ``n_slots`` distinct batches produced once and cycled (the benchmark's
+    ``--data host-u8``: the copy is in the timed region, generation is not).  ``refill=True``: a
+    producer thread regenerates every slot as soon as its copy has left the host — fresh data each
+    step, like a real loader.  ``wait_ms_total()`` = time the host was blocked on the producer."""
 
     def __init__(self, batch_size, num_classes=3, height=224, width=224, channels=3, device="cuda", seed=0,
                  n_slots=4, threads=8, refill=False):
@@ -134,24 +144,49 @@ class PinnedRingSource(object):
         slot_bytes = self.label_off + _align(self.batch_size * 8)
         self.ring = PinnedRing(n_slots, slot_bytes, self.device)
         self.seed, self.threads, self.refill = int(seed), int(threads), bool(refill)
-        self._produced = 0
-        for s in range(n_slots):
-            self._produce(s)
+        self.n = self.ring.n_slots
+        for p in range(self.n):
+            self._produce(p)
+        self._ready_upto = self.n - 1          # productions 0 .. n-1 are in their slots
         self.dev = [(torch.empty(self.shape, dtype=torch.uint8, device=self.device),
                      torch.empty(self.batch_size, dtype=torch.int64, device=self.device)) for _ in range(2)]
         # the generator's pixels are ~N(128, 37) + a class band: (x/64 - 2) keeps activations O(1)
         self.normalization = (1.0 / 64.0, (2.0,) * channels, (1.0,) * channels)
         self._wait_s = 0.0
         self._k = 0
+        self._thread = None
+        if self.refill:
+            import queue
+            import threading
+            self._cv = threading.Condition()
+            self._jobs = queue.Queue()
+            self._thread = threading.Thread(target=self._producer, name="dtp-ring-producer", daemon=True)
+            self._thread.start()
         self._queue(0)
 
-    def _produce(self, slot):
-        self.ring.fill_u8(slot, self.batch_size, self.image_bytes, self.label_off, self.num_classes,
-                          self.seed * 1000003 + self._produced, self.threads)
-        self._produced += 1
+    def _produce(self, p):
+        self.ring.fill_u8(p % self.ring.n_slots, self.batch_size, self.image_bytes, self.label_off, self.num_classes,
+                          self.seed * 1000003 + p, self.threads)
+
+    def _producer(self):
+        while True:
+            p = self._jobs.get()
+            if p is None:
+                return
+            self.ring.host_wait(p % self.n)      # the slot's previous batch has left the host (GIL released)
+            self._produce(p)
+            with self._cv:
+                self._ready_upto = p
+                self._cv.notify_all()
 
     def _queue(self, k):
-        slot = k % self.ring.n_slots
+        if self.refill and k > self._ready_upto:       # production k not in its slot yet: a real data stall
+            t0 = time.perf_counter()
+            with self._cv:
+                while k > self._ready_upto:
+                    self._cv.wait(1.0)
+            self._wait_s += time.perf_counter() - t0
+        slot = k % self.n
         x, y = self.dev[k % 2]
         cs = torch.cuda.current_stream(self.device)
         with trace_range("h2d"):
@@ -164,23 +199,52 @@ class PinnedRingSource(object):
     def __next__(self):
         k = self._k
         self._k += 1
-        self.ring.consumer_wait(k % self.ring.n_slots)          # device-side: compute waits for copy k
-        if self.refill:                                          # fresh data every step (host-side generation)
-            prev = (k - 1) % self.ring.n_slots
-            if k >= 1:
-                if self.ring.slot_busy(prev):
-                    t0 = time.perf_counter()
-                    self.ring.host_wait(prev)
-                    self._wait_s += time.perf_counter() - t0
-                self._produce(prev)
+        self.ring.consumer_wait(k % self.n)              # device-side: compute waits for copy k
         # (without refill the slots are read-only after start-up: nothing on the host ever waits —
         # the host may run several steps ahead of the device, like with device-resident data)
         self._queue(k + 1)
+        if self.refill and k >= 1:
+            self._jobs.put(k - 1 + self.n)               # slot of batch k-1: regenerate once its copy is done
         return self.dev[k % 2]
 
     def wait_ms_total(self):
         return 1e3 * self._wait_s
 
     def close(self):
+        if self._thread is not None:
+            self._jobs.put(None)
+            self._thread.join(timeout=30)
+            self._thread = None
         torch.cuda.synchronize(self.device)
         self.ring.close()
+
+
+class RingSyntheticLoader(object):
+    """DataLoader-shaped face of :class:`PinnedRingSource` for the Trainer: ``len()`` steps per
+    epoch of fresh uint8 batches that are generated by native threads into the pinned ring and
+    arrive on the device through the copy stream (``main.py --synthetic --ring-loader``).  Each rank
+    generates its own stream (seeded by rank), so there is nothing to shard."""
+
+    yields_device_batches = True      # DevicePrefetcher passes these through untouched
+
+    class _Sampler(object):
+        def set_epoch(self, epoch):
+            self.epoch = epoch
+
+    def __init__(self, num_samples, batch_size, num_classes, height, width, device, seed=0, threads=8):
+        self.steps = max(1, num_samples // batch_size)
+        self.sampler = self._Sampler()
+        self.src = PinnedRingSource(batch_size, num_classes, height, width, device=device, seed=seed, n_slots=4,
+                                    threads=threads, refill=True)
+        self.normalization = self.src.normalization
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            x, y = next(self.src)
+            yield [x, y]
+
+    def close(self):
+        self.src.close()

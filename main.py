@@ -43,6 +43,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-progress", action="store_true")
     ap.add_argument("--device-cache", action="store_true",
                     help="materialise the dataset once on the GPU and gather batches there (fits-in-HBM datasets)")
+    ap.add_argument("--ring-loader", action="store_true",
+                    help="synthetic training data from native producer threads through the pinned host ring "
+                         "(uint8 over PCIe on the copy stream); use with --synthetic --no-validate")
     ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (1 process)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + per-bucket sharded optimizer + all-gather instead of all-reduce")
@@ -109,7 +112,7 @@ if __name__ == "__main__":
                              num_workers=args.num_workers,
                              max_steps_per_epoch=args.steps,
                              progress=not args.no_progress, use_hip_graph=args.hip_graph, cache_dataset_on_device=args.device_cache,
-                             shard_optimizer=args.shard_optimizer,
+                             shard_optimizer=args.shard_optimizer, ring_loader=args.ring_loader,
                              metrics_file="%s/metrics.jsonl" % args.save_folder)
 
     trainer.train()
