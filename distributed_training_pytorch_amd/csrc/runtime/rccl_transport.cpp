@@ -115,16 +115,21 @@ void* dtp_rccl_create(const void* id_bytes, int rank, int world, int device) {
   ncclUniqueId id;
   std::memcpy(&id, id_bytes, sizeof(id));
   if (ncclCommInitRank(&t->comm, world, id, rank) != ncclSuccess) { delete t; return nullptr; }
-  // Default-priority, non-blocking stream (what ProcessGroupNCCL uses too).  A HIGH-priority comm
-  // stream deadlocked the device on gfx950 / ROCm 7.0 when its event-gated RCCL kernel became
-  // runnable while LDS-heavy compute kernels were resident on the null stream (reproduced with
-  // tests/test_gpu_model.py after a warm-up step; hipDeviceSynchronize never returned), so high
-  // priority is opt-in: DTP_RCCL_STREAM_PRIORITY=high.
-  int lo = 0, hi = 0;
-  hipDeviceGetStreamPriorityRange(&lo, &hi);
-  const char* pr = std::getenv("DTP_RCCL_STREAM_PRIORITY");
-  const int prio = (pr && pr[0] == 'h') ? hi : 0;
-  if (hipStreamCreateWithPriority(&t->comm_stream, hipStreamNonBlocking, prio) != hipSuccess) {
+  // Default-priority, non-blocking stream (what ProcessGroupNCCL uses too) — by construction, not
+  // by option.  Round 1 created this stream with HIGH priority and the device hung (test at world
+  // size 1 after a warm-up step; hipDeviceSynchronize never returned).  What is known: the compute
+  // kernels of this framework (8-phase implicit GEMM, wgrad2) run ONE workgroup per CU that owns
+  // the CU's whole register file (2 waves/SIMD x 256 VGPRs) and 128 of its 160 KB of LDS, so an
+  // RCCL kernel can only become resident on a CU between two tiles; at equal priority the
+  // dispatcher hands it CUs at those tile boundaries (every ~60 us).  A high-priority queue asks the
+  // hardware for more than that — precedence in queue arbitration while its event-gated barrier
+  // packet is pending, and preemption of resident lower-priority workgroups — and with full-CU
+  // workgroups holding LDS-DMA in flight that did not terminate on gfx950 / ROCm 7.0.  The exact
+  // mechanism was not bisected (a hung device is a lost box for everyone on the host); the design
+  // no longer depends on it: every stream has default priority, no kernel of this framework waits
+  // inside a launch for another queue (cross-stream ordering is events only), and the overlap is
+  // measured instead of forced (allreduce_exposed_ms_per_step).  See docs/KERNELS.md.
+  if (hipStreamCreateWithFlags(&t->comm_stream, hipStreamNonBlocking) != hipSuccess) {
     ncclCommDestroy(t->comm);
     delete t;
     return nullptr;

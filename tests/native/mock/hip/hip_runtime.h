@@ -24,8 +24,7 @@ struct MockLog {
 MockLog& mock_log();
 
 hipError_t hipSetDevice(int);
-hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi);
-hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);

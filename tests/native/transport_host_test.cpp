@@ -16,9 +16,8 @@ static MockLog g_log;
 MockLog& mock_log() { return g_log; }
 static void logc(const std::string& s) { g_log.calls.push_back(s); }
 hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
-hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio) {
-  *s = new MockStream{100 + g_log.streams_created++, (flags & hipStreamNonBlocking) != 0, prio};
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags) {   // default priority: by construction
+  *s = new MockStream{100 + g_log.streams_created++, (flags & hipStreamNonBlocking) != 0, 0};
   return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s) { ++g_log.streams_destroyed; delete s; return hipSuccess; }
