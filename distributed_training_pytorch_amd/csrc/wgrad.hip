@@ -292,252 +292,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 8-phase schedule for the 256x256 tile (same skeleton as igemm.hip PIPE == 2): LDS = 8 half-tile
-// slots of 16 KiB [dbuf][A0, A1, B0, B1]; a half-tile is [64 k-rows][128 channels] (256-byte rows)
-// and holds, for every wave, one half of its channels (A: 64 of its 128 dY channels, B: 32 of its
-// 64 X channels).  Quadrant order A0B0, A0B1, A1B1, A1B0; each phase issues ONE half-tile of
-// LDS-DMA 1.5-2 K-tiles ahead, waits with a counted vmcnt(8), and runs 16 MFMAs between raw
-// s_barriers; the two wave rows are staggered by one barrier.  Fragments come from
-// ds_read_b64_tr_b16 on the s_of<256> swizzle (8 rows x 32 B of a half-wave = 64 distinct banks).
-template <bool TAPS9>
-__global__ __launch_bounds__(512) void wgrad_tt8_kernel(const WgradParams p) {
-  constexpr int BM = 256, BN = 256, BK = 64, SLOT = 16384, RB = 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((ext_vector_type(4))) short s4;
-  typedef __attribute__((address_space(3))) s4* lds_s4;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int ntiles = p.tiles_m * p.tiles_n;
-  const int nsplit_g = gridDim.x / ntiles;
-  const int pair = xcd_remap(blockIdx.x, gridDim.x);
-  const int zsplit = pair / ntiles;
-  const int tile = pair - zsplit * ntiles;
-  const int tn = tile / p.tiles_m, tm = tile - tn * p.tiles_m;
-  const int m0 = tm * BM;
-  int n0, tap = 0, c0 = 0;
-  if (TAPS9) {
-    const int cblocks = p.C / BN;
-    tap = tn / cblocks;
-    c0 = (tn - tap * cblocks) * BN;
-    n0 = tap * p.C + c0;
-  } else {
-    n0 = tn * BN;
-    c0 = n0;
-  }
-  const int dy = TAPS9 ? tap / 3 - 1 : 0, dx = TAPS9 ? tap % 3 - 1 : 0;
-  const int kbeg = zsplit * p.ksteps_per_split;
-  int kend = kbeg + p.ksteps_per_split;
-  if (kend > p.ksteps_total) kend = p.ksteps_total;
-
-  // ---- staging geometry: lane -> (k-row ra (+32 for the second pass), physical chunk pc of 16)
-  const int ra = tid >> 4, pc = tid & 15;
-  const int lc = pc ^ s_of<RB>(ra);                       // logical 16-B chunk (8 channels)
-  const int a_col[2] = {m0 + (lc >> 3) * 128 + (lc & 7) * 8, m0 + (lc >> 3) * 128 + 64 + (lc & 7) * 8};
-  const int b_col[2] = {(lc >> 2) * 64 + (lc & 3) * 8, (lc >> 2) * 64 + 32 + (lc & 3) * 8};   // within the tile
-  const size_t ldb_e = TAPS9 ? (size_t)p.C : (size_t)p.ldb;
-  const size_t a_step = (size_t)BK * p.lda * 2, b_step = (size_t)BK * ldb_e * 2;
-  const size_t a_pass = (size_t)32 * p.lda * 2, b_pass = (size_t)32 * ldb_e * 2;
-  const char* a_src[2];
-  const char* b_src[2];
-  bool a_ok[2], b_ok[2];
-  int a_k[2], b_k[2];                                     // first k-row of the NEXT tile to issue, per half
-  int bh[2][2], bw[2][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    a_ok[h] = a_col[h] < p.lda;
-    a_src[h] = p.dY + ((size_t)(kbeg * BK + ra) * p.lda + a_col[h]) * 2;
-    a_k[h] = b_k[h] = kbeg * BK + ra;
-    if (TAPS9) {
-      b_ok[h] = true;
-      b_src[h] = p.X + ((size_t)((long)(kbeg * BK + ra) + dy * p.W + dx) * p.C + c0 + b_col[h]) * 2;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = kbeg * BK + ra + 32 * j;
-        const int rem = k % (p.H * p.W);
-        bh[h][j] = rem / p.W;
-        bw[h][j] = rem - bh[h][j] * p.W;
-      }
-    } else {
-      b_ok[h] = (n0 + b_col[h]) < p.Ntot;
-      b_src[h] = p.X + ((size_t)(kbeg * BK + ra) * p.ldb + n0 + b_col[h]) * 2;
-    }
-  }
-  const int step_dh = TAPS9 ? BK / p.W : 0;
-  const int step_dw = TAPS9 ? BK - step_dh * p.W : 0;
-  const int k_limit = kend * BK < p.K ? kend * BK : p.K;   // rows at or past it read the zero page
-
-  auto issue_A = [&](auto h_, auto d_) {
-    constexpr int h = decltype(h_)::value, d = decltype(d_)::value;
-    char* dst = smem + (d * 4 + h) * SLOT + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool ok = a_ok[h] && (a_k[h] + 32 * j) < k_limit;
-      glds16(ok ? a_src[h] + j * a_pass : p.zero_page, dst + j * 8192);
-    }
-    a_src[h] += a_step;
-    a_k[h] += BK;
-  };
-  auto issue_B = [&](auto h_, auto d_) {
-    constexpr int h = decltype(h_)::value, d = decltype(d_)::value;
-    char* dst = smem + (d * 4 + 2 + h) * SLOT + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bool ok = b_ok[h] && (b_k[h] + 32 * j) < k_limit;
-      if (TAPS9) {
-        const int hh = bh[h][j] + dy, ww = bw[h][j] + dx;
-        ok = ok && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-        int w2 = bw[h][j] + step_dw, h2 = bh[h][j] + step_dh;
-        if (w2 >= p.W) { w2 -= p.W; h2 += 1; }
-        while (h2 >= p.H) h2 -= p.H;
-        bw[h][j] = w2; bh[h][j] = h2;
-      }
-      glds16(ok ? b_src[h] + j * b_pass : p.zero_page, dst + j * 8192);
-    }
-    b_src[h] += b_step;
-    b_k[h] += BK;
-  };
-
-  // ---- transposed fragment reads
-  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-  const int krow = 8 * g4 + q;
-  const int sw = s_of<RB>(krow);
-  const int sub = pp >> 1, half8 = (pp & 1) * 8;
-  const int rd_row = krow * RB + half8;
-  int a_off[4], b_off[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) a_off[i] = rd_row + ((((wm * 8 + 2 * i) ^ sw) + sub) << 4);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) b_off[j] = rd_row + ((((wn * 4 + 2 * j) ^ sw) + sub) << 4);
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t xa[2][4], b0f[2][2], b1f[2][2];
-
-#define WG_TR(dst, addr)                                                                     \
-  {                                                                                          \
-    const s4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(addr));                  \
-    const s4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)((addr) + 4 * RB));       \
-    dst = (bf16x8_t){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};        \
-  }
-#define WG_READ_A(h, d)                                                                      \
-  {                                                                                          \
-    const char* s_ = smem + ((d) * 4 + (h)) * SLOT;                                          \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-        WG_TR(xa[ks][i], s_ + ks * 32 * RB + a_off[i])                                       \
-  }
-#define WG_READ_B(h, d, dst)                                                                 \
-  {                                                                                          \
-    const char* s_ = smem + ((d) * 4 + 2 + (h)) * SLOT;                                      \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-        WG_TR(dst[ks][j], s_ + ks * 32 * RB + b_off[j])                                      \
-  }
-#define WG_MMA(mh, nh, bf)                                                                   \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(mh) * 4 + i][(nh) * 2 + j] =        \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], xa[ks][i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);
-#define WG_SYNC_IN()                                          \
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            \
-  __builtin_amdgcn_s_barrier();                               \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  __builtin_amdgcn_s_setprio(1);
-#define WG_SYNC_OUT()                                         \
-  __builtin_amdgcn_s_setprio(0);                              \
-  __builtin_amdgcn_sched_barrier(0);                          \
-  __builtin_amdgcn_s_barrier();                               \
-  __builtin_amdgcn_sched_barrier(0);
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-
-  // prologue: tile kbeg entirely, B0/A0 of tile kbeg+1 (issue order = consumption order)
-  issue_B(I0{}, I0{});
-  issue_A(I0{}, I0{});
-  issue_B(I1{}, I0{});
-  issue_A(I1{}, I0{});
-  issue_B(I0{}, I1{});
-  issue_A(I0{}, I1{});
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int t = kbeg; t < kend; t += 2) {
-    WG_READ_A(0, 0) WG_READ_B(0, 0, b0f)                  // P1
-    issue_B(I1{}, I1{});
-    WG_SYNC_IN(); WG_MMA(0, 0, b0f) WG_SYNC_OUT();
-    WG_READ_B(1, 0, b1f)                                  // P2
-    issue_A(I1{}, I1{});
-    WG_SYNC_IN(); WG_MMA(0, 1, b1f) WG_SYNC_OUT();
-    WG_READ_A(1, 0)                                       // P3
-    issue_B(I0{}, I0{});
-    WG_SYNC_IN(); WG_MMA(1, 1, b1f) WG_SYNC_OUT();
-    issue_A(I0{}, I0{});                                  // P4
-    WG_SYNC_IN(); WG_MMA(1, 0, b0f) WG_SYNC_OUT();
-    WG_READ_A(0, 1) WG_READ_B(0, 1, b0f)                  // P5 (an all-zero tile when the count is odd)
-    issue_B(I1{}, I0{});
-    WG_SYNC_IN(); WG_MMA(0, 0, b0f) WG_SYNC_OUT();
-    WG_READ_B(1, 1, b1f)                                  // P6
-    issue_A(I1{}, I0{});
-    WG_SYNC_IN(); WG_MMA(0, 1, b1f) WG_SYNC_OUT();
-    WG_READ_A(1, 1)                                       // P7
-    issue_B(I0{}, I1{});
-    WG_SYNC_IN(); WG_MMA(1, 1, b1f) WG_SYNC_OUT();
-    issue_A(I0{}, I1{});                                  // P8
-    WG_SYNC_IN(); WG_MMA(1, 0, b0f) WG_SYNC_OUT();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef WG_TR
-#undef WG_READ_A
-#undef WG_READ_B
-#undef WG_MMA
-#undef WG_SYNC_IN
-#undef WG_SYNC_OUT
-
-  // ---- epilogue (same ownership as wgrad_tt_kernel: lane owns dW[m = .. + li][n .. n+3])
-  const bool direct = nsplit_g == 1;
-  float* slab = p.partial + (size_t)zsplit * p.M * p.Ntot;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + li;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + g4 * 4;
-      if (n >= p.Ntot) continue;
-      const size_t o = (size_t)m * p.Ntot + n;
-      f32x4_t v = acc[i][j];
-      if (!direct) {
-        *(f32x4_t*)(slab + o) = v;
-      } else if (p.out_fp32) {
-        float* d = (float*)p.out + o;
-        if (p.beta != 0.f) v = v + *(const f32x4_t*)d * p.beta;
-        *(f32x4_t*)d = v;
-      } else {
-        bf16_t* d = (bf16_t*)p.out + o;
-        if (p.beta != 0.f) {
-          const u32x2_t old = *(const u32x2_t*)d;
-          v[0] += p.beta * bf16_to_f32((bf16_t)(old[0] & 0xFFFFu));
-          v[1] += p.beta * bf16_to_f32((bf16_t)(old[0] >> 16));
-          v[2] += p.beta * bf16_to_f32((bf16_t)(old[1] & 0xFFFFu));
-          v[3] += p.beta * bf16_to_f32((bf16_t)(old[1] >> 16));
-        }
-        u32x2_t pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
-        *(u32x2_t*)d = pk;
-      }
-    }
-  }
-}
-
 // out = beta*out + sum_z partial[z]   (vectorised x4; total is a multiple of 4)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, size_t total,
                                     void* __restrict__ out, int out_fp32, float beta) {
@@ -590,28 +344,6 @@ static int launch_wg(const WgradParams& p0, int nsplit, hipStream_t stream) {
   return DTP_CHECK_LAUNCH();
 }
 
-template <bool TAPS9>
-static int launch_wg8(const WgradParams& p0, int nsplit, hipStream_t stream) {
-  WgradParams p = p0;
-  p.tiles_m = (p.M + 255) / 256;
-  if (TAPS9) {
-    if (p.C % 256 != 0) return -20;
-    p.tiles_n = 9 * (p.C / 256);
-  } else {
-    p.tiles_n = (p.Ntot + 255) / 256;
-  }
-  constexpr int lds = 8 * 16384;
-  static bool attr_set = false;
-  auto kern = wgrad_tt8_kernel<TAPS9>;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return -2;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n * nsplit), dim3(512), lds, stream, p);
-  return DTP_CHECK_LAUNCH();
-}
-
 // second-generation kernels (csrc/wgrad2.hip): cfg 8 = 256x256 tile, cfg 9 = 128x128 tile
 extern "C" int dtp_wgrad_tt2_launch(const void* dY, const void* X, void* out, float* partial, int K, int M, int Ntot,
                                     int C, int taps, int H, int W, int lda, int ldb, int out_fp32, float beta,
@@ -652,7 +384,6 @@ extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* par
                     : launch_wg<256, 256, 2, 4, false, true>(p, nsplit, stream); break;
     case 7: rc = t9 ? launch_wg<128, 128, 2, 2, true, true>(p, nsplit, stream)
                     : launch_wg<128, 128, 2, 2, false, true>(p, nsplit, stream); break;
-    case 5: rc = t9 ? launch_wg8<true>(p, nsplit, stream) : launch_wg8<false>(p, nsplit, stream); break;
     case 8: case 9:
       if (t9 && (C % (cfg == 8 ? 256 : 128))) return -20;
       rc = dtp_wgrad_tt2_launch(dY, X, out, partial, K, M, Ntot, C, taps, H, W, lda, ldb, out_fp32, beta, nsplit,

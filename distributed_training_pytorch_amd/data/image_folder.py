@@ -6,13 +6,25 @@ CLAHE / brightness-contrast / gamma / JPEG compression (each p=0.5) + ImageNet n
 pipeline = resize + normalise; returns ``(float32 CHW tensor, int label)``.
 
 cv2, albumentations and torchvision are not installable here, so decoding uses PIL
-and the augmentations are re-implemented on numpy/PIL: rot90, flips, box blur, median filter,
-brightness/contrast, gamma and JPEG re-compression are functional equivalents; CLAHE is
-approximated by PIL's global ``ImageOps.equalize`` blended 50/50, and the blur / median kernel
-ranges (albumentations defaults: blur_limit 3..7) are sampled from {1, 2, 3} box radii and {3, 5}
-median sizes ("parity unpinned": albumentations / cv2 cannot be installed here and no reference
-fixture pins augmentation outputs, so the transforms are functional stand-ins, not bit matches).  The file order is deterministic and identical on
-every rank (quirk #3): shuffling is the sampler's job.
+and the augmentations are re-implemented on numpy/PIL with the parameter ranges albumentations'
+defaults give the reference's calls:
+
+* ``RandomRotate90``: k in {0..3} quarter turns (square targets only: a non-square rotate would
+  change the batch shape); ``HorizontalFlip`` / ``VerticalFlip``.
+* ``Blur()``: box filter, odd kernel in {3, 5, 7} (blur_limit 3..7) = PIL ``BoxBlur`` radius {1, 2, 3}.
+* ``MedianBlur()``: odd kernel in {3, 5, 7}.
+* ``CLAHE()``: clip limit uniform in [1, 4], 8x8 tile grid, applied to the luminance — ``clahe()``
+  below is the tile-histogram / clip / redistribute / bilinear-LUT algorithm itself (the reference
+  gets it from cv2 on the L channel of LAB; here it runs on Y of YCbCr, PIL having no LAB).
+* ``RandomBrightnessContrast()``: ``clip(x * (1 + c) + b * 255)``, c, b uniform in [-0.2, 0.2]
+  (albumentations' ``brightness_by_max=True`` uint8 path — NOT mean-centred).
+* ``RandomGamma()``: gamma uniform in [0.8, 1.2]; ``ImageCompression(20, 100)``: JPEG round trip.
+
+"Parity unpinned": neither library can be installed here and no reference fixture pins an
+augmentation output, so these follow the documented algorithms and ranges but are not bit
+matches (border handling of the blurs, PIL's antialiased bilinear resize vs cv2 INTER_LINEAR).
+The file order is deterministic and identical on every rank (quirk #3): shuffling is the
+sampler's job.
 """
 import io
 import os
@@ -30,6 +42,46 @@ IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".ppm", ".webp")
 def _pil():
     from PIL import Image, ImageFilter, ImageOps
     return Image, ImageFilter, ImageOps
+
+
+def clahe(gray, clip_limit=4.0, grid=(8, 8)):
+    """Contrast-limited adaptive histogram equalisation of a uint8 [H][W] plane.
+
+    Per tile of the ``grid``: 256-bin histogram, bins clipped at ``clip_limit * tile_pixels / 256``
+    (at least 1), the clipped mass redistributed evenly (remainder spread with a stride, as cv2
+    does), LUT = round(cdf * 255 / tile_pixels); every pixel is mapped through the four LUTs of
+    the tiles around it, blended bilinearly between tile centres.  The plane is edge-padded
+    (reflect) to a multiple of the grid first."""
+    gray = np.ascontiguousarray(gray, dtype=np.uint8)
+    H, W = gray.shape
+    gy, gx = int(grid[0]), int(grid[1])
+    ph, pw = (-H) % gy, (-W) % gx
+    src = np.pad(gray, ((0, ph), (0, pw)), mode="reflect") if (ph or pw) else gray
+    th, tw = src.shape[0] // gy, src.shape[1] // gx
+    area = th * tw
+    limit = max(int(clip_limit * area / 256.0), 1) if clip_limit > 0 else area
+    tiles = src.reshape(gy, th, gx, tw).transpose(0, 2, 1, 3).reshape(gy * gx, area)
+    hist = np.stack([np.bincount(t, minlength=256) for t in tiles]).astype(np.int64)   # [tiles][256]
+    excess = np.maximum(hist - limit, 0).sum(axis=1)
+    hist = np.minimum(hist, limit)
+    hist += (excess // 256)[:, None]
+    residual = excess % 256
+    for t in np.nonzero(residual)[0]:
+        step = max(256 // int(residual[t]), 1)
+        hist[t, np.arange(0, 256, step)[:int(residual[t])]] += 1
+    lut = np.clip(np.rint(np.cumsum(hist, axis=1) * (255.0 / area)), 0, 255).astype(np.float32)
+    lut = lut.reshape(gy, gx, 256)
+    # bilinear blend between tile centres
+    yy = (np.arange(H, dtype=np.float32) + 0.5) / th - 0.5
+    xx = (np.arange(W, dtype=np.float32) + 0.5) / tw - 0.5
+    y0 = np.floor(yy).astype(np.int64); x0 = np.floor(xx).astype(np.int64)
+    wy = (yy - y0).astype(np.float32)[:, None]; wx = (xx - x0).astype(np.float32)[None, :]
+    y1 = np.clip(y0 + 1, 0, gy - 1)[:, None]; x1 = np.clip(x0 + 1, 0, gx - 1)[None, :]
+    y0 = np.clip(y0, 0, gy - 1)[:, None]; x0 = np.clip(x0, 0, gx - 1)[None, :]
+    v = gray.astype(np.int64)
+    out = ((1 - wy) * ((1 - wx) * lut[y0, x0, v] + wx * lut[y0, x1, v])
+           + wy * ((1 - wx) * lut[y1, x0, v] + wx * lut[y1, x1, v]))
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
 class ExampleDataset(Dataset):
@@ -87,14 +139,16 @@ class ExampleDataset(Dataset):
         if r.random() < p:
             img = img.filter(ImageFilter.BoxBlur(r.choice([1, 2, 3])))
         if r.random() < p:
-            img = img.filter(ImageFilter.MedianFilter(size=r.choice([3, 5])))
+            img = img.filter(ImageFilter.MedianFilter(size=r.choice([3, 5, 7])))
         if r.random() < p:
-            img = Image.blend(img, ImageOps.equalize(img), 0.5)
+            ycc = np.array(img.convert("YCbCr"))
+            ycc[..., 0] = clahe(ycc[..., 0], clip_limit=r.uniform(1.0, 4.0), grid=(8, 8))
+            img = Image.fromarray(ycc, mode="YCbCr").convert("RGB")
         if r.random() < p:
             a = np.asarray(img, dtype=np.float32)
             alpha = 1.0 + r.uniform(-0.2, 0.2)
             beta = r.uniform(-0.2, 0.2) * 255.0
-            a = np.clip((a - a.mean()) * alpha + a.mean() + beta, 0, 255)
+            a = np.clip(a * alpha + beta, 0, 255)
             img = Image.fromarray(a.astype(np.uint8))
         if r.random() < p:
             gamma = r.uniform(0.8, 1.2)

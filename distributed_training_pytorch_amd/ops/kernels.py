@@ -20,8 +20,8 @@ N_CU = 256
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
-WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64), 5: (256, 256),
-               6: (256, 256), 7: (128, 128),   # 5: 8-phase port, 6/7: software-pipelined fragment reads
+WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64),
+               6: (256, 256), 7: (128, 128),   # 6/7: software-pipelined fragment reads (5 was an 8-phase port: slower, deleted)
                8: (256, 256), 9: (128, 128)}   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}

@@ -4,9 +4,9 @@ Parity target: reference ``trainer/trainer.py:215`` uses ``DistributedSampler(da
 shuffle=True)`` and ``:140`` calls ``sampler.set_epoch(epoch)``.  This sampler produces the *same
 index sequence* as ``torch.utils.data.DistributedSampler`` with seed 0 (permutation from
 ``torch.Generator().manual_seed(seed + epoch)``, padded by wrapping to a multiple of the world
-size, strided slice ``rank::world``) — tests/test_sampler.py pins that — but takes rank/world
-explicitly, so it works without a process group (single-GPU runs, unit tests) and supports
-``drop_last`` and resuming mid-epoch via ``start_index``.
+size, strided slice ``rank::world``) — tests/test_unit_cpu.py pins that — but takes rank/world
+explicitly, so it works without a process group (single-GPU runs, unit tests), and supports
+``drop_last`` and unpadded shards (``pad=False``: validation without duplicated samples).
 """
 import math
 
@@ -28,7 +28,6 @@ class ShardedSampler(Sampler):
         self.drop_last = bool(drop_last)
         self.pad = bool(pad)        # pad=False: no duplicated samples; shards may differ by one
         self.epoch = 0
-        self.start_index = 0
         if self.drop_last and self.n % self.world_size != 0:
             self.num_samples = math.ceil((self.n - self.world_size) / self.world_size)
         else:
@@ -40,7 +39,6 @@ class ShardedSampler(Sampler):
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
-        self.start_index = 0
 
     def global_order(self):
         if self.shuffle:
@@ -63,8 +61,7 @@ class ShardedSampler(Sampler):
         return idx
 
     def __iter__(self):
-        idx = self.global_order()[self.rank:self.total_size:self.world_size]
-        return iter(idx[self.start_index:])
+        return iter(self.global_order()[self.rank:self.total_size:self.world_size])
 
     def __len__(self):
-        return self.num_samples - self.start_index
+        return self.num_samples

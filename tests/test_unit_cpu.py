@@ -409,3 +409,25 @@ def test_device_cached_loader_matches_dataloader_batches():
             cached.sampler.set_epoch(epoch)
             for (xa, ya), (xb, yb) in zip(ref, cached):
                 assert torch.equal(xa, xb) and torch.equal(ya, yb)
+
+
+def test_clahe_algorithm():
+    """data/image_folder.clahe: with one tile and no effective clip limit it IS global histogram
+    equalisation (closed form), with the 8x8 grid it raises local contrast, keeps the shape for
+    sizes that are not multiples of the grid, and a low clip limit changes the image less than a
+    high one (reference: A.CLAHE at dataset/example_dataset.py:41; parity unpinned, see module doc)."""
+    import numpy as np
+    from distributed_training_pytorch_amd.data.image_folder import clahe
+    rng = np.random.default_rng(0)
+    g = (100 + 40 * rng.random((224, 224))).astype(np.uint8)
+    cdf = np.cumsum(np.bincount(g.ravel(), minlength=256)) * 255.0 / g.size
+    assert np.array_equal(clahe(g, 1e9, (1, 1)), np.rint(cdf[g]).astype(np.uint8))
+    lo, hi = clahe(g, 1.0), clahe(g, 4.0)
+    assert g.std() < lo.std() < hi.std()
+    odd = rng.integers(0, 256, (225, 230)).astype(np.uint8)
+    out = clahe(odd, 3.0)
+    assert out.shape == odd.shape and out.dtype == np.uint8
+    # monotone inside a tile neighbourhood: equalisation never swaps the order of two grey levels
+    ramp = np.tile(np.arange(224, dtype=np.uint8), (224, 1))
+    r = clahe(ramp, 2.0).astype(int)
+    assert (np.diff(r[:, 4:24], axis=1) >= 0).all()
