@@ -41,8 +41,11 @@ def _newer(src_list, target):
 def _compile_hip(src, headers, extra=()):
     obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
     if _newer([src] + headers, obj):
+        # DTP_BUILD_DEFS: extra defines for diagnostic builds (e.g. "-DDTP_C64_STAMPS": in-kernel time
+        # stamps of conv_c64, bench/stamp_c64.py); touch the source to force its rebuild
+        defs = os.environ.get("DTP_BUILD_DEFS", "").split()
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-              "-I", CSRC, *extra, "-c", src, "-o", obj])
+              "-I", CSRC, *extra, *defs, "-c", src, "-o", obj])
     return obj
 
 

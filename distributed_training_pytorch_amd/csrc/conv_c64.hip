@@ -17,6 +17,7 @@
 // Borders / strip tails are redirected per lane to a zeroed page.  XOR swizzle (chunk ^= (pos>>1)&7)
 // on the DMA source address and on the reads keeps the 32-row fragment reads conflict-free.
 #include "dtp_common.h"
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -36,16 +37,39 @@ struct ConvC64Params {
   int S, RC, rows_per_chunk;
   int relu;
   float mask_scale;
+  unsigned long long* stamps;   // DEBUG (DTP_C64_STAMPS): per workgroup, first 16 row steps x 6 stamps (bench/stamp_c64.py)
 };
 
-template <int O, bool POOL>
+// LDS ops the compiler does not track (counted waits, see dtp_common.h DTP_DSR128)
+#define C64_DSW64(addr, data) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(data) : "memory")
+#define C64_NAME2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define C64_NAME4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+
+// Row step = 36 MFMAs on ONE accumulator chain.  In-kernel stamps (bench/stamp_c64.py) showed a wave
+// spending 4,100 cycles per step for 1,152 cycles of matrix work — the same at one and at two waves
+// per SIMD: not pipe contention but the step's serial chain (DMA wait + barrier 500, LDS-DMA issue
+// ~400, exposed first-tap read latency, 4 reads between every 4 MFMAs, then bias / ReLU / pack / LDS
+// shuffle 640 and store issue 490 with the matrix pipe idle).  This version keeps the chain short:
+//   * fragment reads are issued ONE PER MFMA, four MFMAs ahead, with a counted lgkmcnt in front of
+//     each MFMA — no read burst between taps;
+//   * the accumulator is initialised with the bias by four LDS reads straight into its registers;
+//   * the finished row is only rounded, ReLU'd and parked in a per-wave LDS row buffer (24 VALU +
+//     4 ds_write_b64); its shuffle read-back, masking, stores and 1-bit masks — or the 2x2 max-pool
+//     of a finished row pair with its argmax codes — run in the gaps of the NEXT row's MFMAs;
+//   * the workgroup barrier sits after tap 2 (the last read of ring row h-1): the LDS-DMA of row
+//     h+3 that follows it has two row steps to land, and the deferred stores issued right after it
+//     are a full step old when the next `vmcnt(0)` comes.
+template <int O, bool POOL, bool MASK>
 __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params p) {
   constexpr int NW = O / 32;             // waves per workgroup (2 or 4)
-  constexpr int X_SLOT = 40 * 128;
-  constexpr int X_WI = 5;
+  constexpr int PW = NW == 2 ? 3 : 2;    // LDS-DMA pieces (8 ring positions, 1 KiB) per wave and row
+  constexpr int X_SLOT = PW * NW * 1024; // 48 / 64 ring positions: 34 used, the rest take hardware zeros
+  constexpr int ND = POOL ? 4 : 2;       // deferred LDS reads per step (always issued: the counted waits assume them)
+  constexpr unsigned BAD = 0x40000000u;  // half of an out-of-range offset: row part + column part, either or both BAD, stay out of range
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lX = smem;                       // 4 ring slots
-  char* lO = smem + 4 * X_SLOT;          // per-wave 2 KiB output shuffle
+  char* lX = smem;                       // 4 ring slots: row r lives in slot (r + 1) & 3
+  char* lO = smem + 4 * X_SLOT;          // per wave: two 2 KiB row buffers [32 px][32 cout] bf16
+  float* lBias = (float*)(lO + NW * 4096);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,6 +84,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   int h1 = h0 + p.rows_per_chunk;
   if (h1 > p.H) h1 = p.H;
   const size_t img_px = (size_t)n * p.H * p.W;
+  const int OHp = p.H >> 1, OWp = p.W >> 1;
 
   // ---- this wave's filter slice -> registers: A operand, lane = (row cout = l31, k = 8*hb + j)
   bf16x8_t wf[9][4];
@@ -70,247 +95,285 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #pragma unroll
       for (int k = 0; k < 4; ++k) wf[t][k] = *(const bf16x8_t*)(wbase + (t * 64 + k * 16) * 2);
   }
-  // accumulator row (cout within the wave's 32) of register r: (r&3) + 8*(r>>2) + 4*hb.  The bias
-  // sits in LDS and is added after the MFMAs: 16 registers less than a register-resident copy, which
-  // lets the fragment reads run one tap (4 x ds_read_b128) ahead of the MFMAs.
-  float* lBias = (float*)(smem + 4 * X_SLOT + NW * 2048 + O * 2 * 32);
   if (tid < O) lBias[tid] = p.bias ? p.bias[tid] : 0.f;
 
-  // ---- ring staging geometry
-  const int xr = lane >> 3, xpc = lane & 7;
-  auto stage_x = [&](int hrow) {
-    char* slot = lX + ((hrow + 1) & 3) * X_SLOT;
-    const bool row_ok = hrow >= 0 && hrow < p.H;
+  // ---- per-image buffer descriptors: every tail (image border, strip tail, rows past the chunk,
+  // "nothing parked yet", absent 1-bit-mask / stamp buffers) is an out-of-range offset — loads give
+  // zeros (LDS-DMA: zeros written to LDS), stores are dropped — so a row step is ONE basic block and
+  // hipcc can spread the deferred epilogue between the MFMAs.
+  const long x_img_bytes = ((long)p.H * p.W - 1) * p.ldx * 2 + 128;
+  const __amdgpu_buffer_rsrc_t x_rs = make_rsrc(p.X + img_px * p.ldx * 2, x_img_bytes);
+  const long o_img_bytes = POOL ? (long)OHp * OWp * O * 2 : (long)p.H * p.W * O * 2;
+  const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + (size_t)n * o_img_bytes, o_img_bytes);
+  const __amdgpu_buffer_rsrc_t m_rs = make_rsrc(MASK ? p.mask_src + (size_t)n * o_img_bytes : nullptr, MASK ? o_img_bytes : 0);
+  // second output: !POOL 1-bit masks (1 byte per 16-byte chunk), POOL argmax codes (4 bytes per 16-byte chunk)
+  const long b_img_bytes = POOL ? o_img_bytes / 4 : o_img_bytes / 16;
+  const char* b_base = POOL ? (const char*)p.codes : (const char*)p.bits_out;
+  const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(b_base ? b_base + (size_t)n * b_img_bytes : nullptr, b_base ? b_img_bytes : 0);
+
+  // ---- ring staging: piece k of this wave covers ring positions (wave + k*NW)*8 .. +7
+  unsigned xcol[PW];
 #pragma unroll
-    for (int k = 0; k < (X_WI + NW - 1) / NW; ++k) {
-      const int wi = wave + k * NW;
-      if (wi < X_WI) {
-        const int pos = wi * 8 + xr;
-        const int w = w0 - 1 + pos;
-        const bool ok = row_ok && pos < 34 && w >= 0 && w < p.W;
-        const int lc = xpc ^ ((pos >> 1) & 7);
-        const char* g = ok ? p.X + ((img_px + (size_t)hrow * p.W + w) * p.ldx + lc * 8) * 2 : p.zero_page;
-        glds16(g, slot + wi * 1024);
-      }
-    }
+  for (int k = 0; k < PW; ++k) {
+    const int pos = (wave + k * NW) * 8 + (lane >> 3);
+    const int w = w0 - 1 + pos;
+    const int lc = (lane & 7) ^ ((pos >> 1) & 7);
+    xcol[k] = (pos < 34 && w >= 0 && w < p.W) ? (unsigned)((w * p.ldx + lc * 8) * 2) : BAD;
+  }
+  const unsigned x_row_bytes = (unsigned)(p.W * p.ldx * 2);
+  auto stage_x = [&](int hrow) {
+    char* slot = lX + ((hrow + 1) & 3) * X_SLOT + wave * 1024;
+    const unsigned roff = (hrow >= 0 && hrow < p.H && hrow <= h1) ? (unsigned)hrow * x_row_bytes : BAD;
+#pragma unroll
+    for (int k = 0; k < PW; ++k) glds16_buf(x_rs, xcol[k] + roff, slot + k * NW * 1024);
   };
   // fragment read geometry: B operand, lane = (col px = l31, k = 8*hb + j); ring position px+dx+1
-  int xoff[3][4];
+  // byte offset of fragment k at ring position pos = l31 + d: pos*128 + (((2k + hb) ^ ((pos>>1)&7)) << 4)
+  //   = xo[d] ^ (k << 5)   (2k only touches chunk bits 1..2): three registers instead of twelve
+  int xo[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int pos = l31 + d;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xoff[d][k] = pos * 128 + ((((2 * k + hb) ^ ((pos >> 1) & 7))) << 4);
+    xo[d] = pos * 128 + ((hb ^ ((pos >> 1) & 7)) << 4);
   }
-  char* myO = lO + wave * 2048;
-  const bool px_ok = (w0 + l31) < p.W;
+  const unsigned lx0 = lds_addr(lX);
+  const unsigned myO = lds_addr(lO + wave * 4096);
+  // accumulator register 4q + e = cout 8q + 4hb + e of pixel l31: bias as four 16-byte LDS reads
+  const unsigned bias_a = lds_addr(lBias) + (wave * 32 + 4 * hb) * 4;
+  // row buffer: pixel px = 64 bytes = four 16-byte chunks (8 couts), chunk c stored at c ^ ((px >> 2) & 3)
+  const unsigned wr_a = myO + l31 * 64 + hb * 8;
+  const int wr_sw = (l31 >> 2) & 3;
+  // deferred read-back geometry
+  //   !POOL: lane = (px = lane/4 + 16r, chunk = lane%4): one 16-byte row segment per read / store
+  //   POOL:  lane = (pooled px pp = lane/4, chunk = lane%4): pixels 2pp, 2pp+1 of both row buffers
+  const int dch = lane & 3;
+  unsigned rd_a[2], ocol[2];             // ocol: column part of the output byte offset inside the image
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int px = POOL ? 2 * (lane >> 2) + r : (lane >> 2) + 16 * r;
+    rd_a[r] = myO + px * 64 + ((dch ^ ((px >> 2) & 3)) << 4);
+    if (POOL) {
+      const int pp = lane >> 2;
+      ocol[r] = (w0 + 2 * pp) < p.W ? (unsigned)((((w0 >> 1) + pp) * O + wave * 32 + dch * 8) * 2) : BAD;
+    } else {
+      ocol[r] = (w0 + px) < p.W ? (unsigned)(((w0 + px) * O + wave * 32 + dch * 8) * 2) : BAD;
+    }
+  }
+  const unsigned o_row_bytes = (unsigned)((POOL ? OWp : p.W) * O * 2);
 
-  uint32_t top_a = 0;
-  char* myT = lO + NW * 2048 + tid * 32;   // POOL: per-lane parking slot for the top row of a window
+  u32x4_t st[4];                         // read-back of the parked row(s)
+  u32x4_t mk[2];                         // MASK: bf16 ReLU-mask source of the parked row
+  auto deferred_reads = [&](unsigned row_off) {    // row_off: byte offset of the parked row in the image, or BAD
+    DTP_DSR128(st[0], rd_a[0]);
+    DTP_DSR128(st[1], rd_a[1]);
+    if constexpr (POOL) {
+      DTP_DSR128(st[2], rd_a[0] + 2048);
+      DTP_DSR128(st[3], rd_a[1] + 2048);
+    }
+    if constexpr (MASK) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        mk[r] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(m_rs, (int)(ocol[r] + row_off), 0, 0));
+    }
+  };
+  // !POOL: the parked row -> global (mask, 1-bit masks); st[] complete (see the callers)
+  auto deferred_store = [&](unsigned row_off) {
+    C64_NAME2(st[0], st[1]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      u32x4_t v = st[r];
+      const unsigned off = ocol[r] + row_off;
+      if constexpr (MASK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t mw = mk[r][e], vw = v[e];
+          const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
+          const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
+          const float a = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+          const float b = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+          v[e] = pack_bf16x2(a, b);
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (int)off, 0, 0);
+      // (x > 0) per bf16 half as clamp((int16)x, 0, 1): two packed ops per word, then 2 bits per word
+      typedef short s16x2_t __attribute__((ext_vector_type(2)));
+      uint32_t b = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const s16x2_t c = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(s16x2_t, v[e]), (s16x2_t){1, 1}), (s16x2_t){0, 0});
+        const uint32_t cw = __builtin_bit_cast(uint32_t, c);
+        b |= ((cw | (cw >> 15)) & 3u) << (2 * e);
+      }
+      __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, b_rs, (int)(off >> 4), 0, 0);
+    }
+  };
+  // POOL: 2x2/s2 max over the two parked rows (top = buffer 0, bottom = buffer 1), 8 channels of one
+  // pooled pixel per lane.  The values are post-ReLU bf16 (non-negative), so their bit patterns
+  // order like the numbers; tie rule = torch's (first maximum in (0,0),(0,1),(1,0),(1,1) order);
+  // code nibble = argmax | (max > 0) << 2.
+  u32x4_t pool_v;
+  uint32_t pool_code;
+  auto pool_word = [&](int j) {
+    uint32_t outw = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t A = (st[0][j] >> (16 * half)) & 0xFFFFu, B = (st[1][j] >> (16 * half)) & 0xFFFFu;
+      const uint32_t C = (st[2][j] >> (16 * half)) & 0xFFFFu, D = (st[3][j] >> (16 * half)) & 0xFFFFu;
+      const uint32_t ta = B > A ? 1u : 0u, t = B > A ? B : A;
+      const uint32_t ua = D > C ? 1u : 0u, u = D > C ? D : C;
+      const bool take_u = u > t;
+      const uint32_t m = take_u ? u : t;
+      const uint32_t nib = (take_u ? 2u + ua : ta) | (m != 0u ? 4u : 0u);
+      outw |= m << (16 * half);
+      pool_code |= nib << (8 * j + 4 * half);
+    }
+    pool_v[j] = outw;
+  };
+  auto pool_store = [&](unsigned row_off) {
+    const unsigned off = ocol[0] + row_off;
+    __builtin_amdgcn_raw_buffer_store_b128(pool_v, o_rs, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(pool_code, b_rs, (int)(off >> 2), 0, 0);
+  };
+
+#ifdef DTP_C64_STAMPS   // diagnostic build only (DTP_BUILD_DEFS=-DDTP_C64_STAMPS): the production kernel holds no stamp code
+#define C64_STAMP(i) if (p.stamps && tid == 0 && h - h0 < 16) p.stamps[((size_t)blockIdx.x * 16 + (h - h0)) * 6 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define C64_STAMP(i)
+#endif
   stage_x(h0 - 1);
   stage_x(h0);
   stage_x(h0 + 1);
+  stage_x(h0 + 2);
+  sync_lds_dma();                        // ring rows h0-1 .. h0+2 and the bias are in LDS
   for (int h = h0; h < h1; ++h) {
-    sync_lds_dma();                      // row h+1 landed (explicit vmcnt(0) + barrier); step h-1 done everywhere
-    if (h + 1 < h1) stage_x(h + 2);
-    // earlier partial sums (two-pass 128-channel reduction): issued now, added after the MFMAs.
-    // Register r holds cout 8*(r>>2) + 4*hb + (r&3) of pixel l31 -> four 8-byte loads per lane.
-    u32x2_t pv[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
-    if (!POOL && p.acc_src && px_ok) {
+    C64_STAMP(0)
+    // parked work from earlier rows: its output row offset in the image, BAD when there is none
+    const bool pend = POOL ? (h > h0 && ((h - h0) & 1) == 0) : h > h0;
+    const unsigned prev_off = pend ? (unsigned)(POOL ? (h - 1) >> 1 : h - 1) * o_row_bytes : BAD;
+    unsigned sl[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sl[d] = lx0 + ((h + d) & 3) * X_SLOT;    // rows h-1, h, h+1
+    u32x4_t bq[4], xf[2][4];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) DTP_DSR128(bq[q], bias_a + q * 32);
+#define C64_RD(i) DTP_DSR128(xf[((i) / 4) & 1][(i) % 4], (sl[(i) / 12] + xo[((i) / 4) % 3]) ^ (((i) % 4) << 5));
+    C64_RD(0) C64_RD(1) C64_RD(2) C64_RD(3)
+    f32x16_t acc;
+    // (a macro per step, not a `#pragma unroll` loop: hipcc left the loop rolled and sent the
+    // filter registers to scratch)
+    // LDS ops younger than read i when MFMA i issues: reads i+1 .. i+3, and for i = 2 .. 5 the ND
+    // deferred reads issued behind read 5
+#define C64_YOUNG(i) ((35 - (i) < 3 ? 35 - (i) : 3) + (((i) >= 2 && (i) <= 5) ? ND : 0))
+#ifdef DTP_C64_FENCED
+#define C64_SB __builtin_amdgcn_sched_barrier(0);
+#else
+#define C64_SB
+#endif
+#define C64_STEP(i)                                                                                          \
+  {                                                                                                          \
+    if ((i) == 0) {                                                                                          \
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xf[0][0]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])); \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)            \
+          acc[q * 4 + e] = __uint_as_float(bq[q][e]);                                                        \
+    } else {                                                                                                 \
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[((i) / 4) & 1][(i) % 4]) : "n"(C64_YOUNG(i)));          \
+    }                                                                                                        \
+    C64_SB                                                                                                   \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(i) / 4][(i) % 4],                                      \
+                                                  __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), acc, 0, 0, 0); \
+    C64_SB                                                                                                   \
+    if ((i) + 4 < 36) { C64_RD(((i) + 4 < 36 ? (i) + 4 : 0)) }                                               \
+    if ((i) == 1) {                                                                                          \
+      deferred_reads(prev_off);                                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    if ((i) == 11) {                                                                                         \
+      /* every wave is past its last read of ring row h-1 (reads 0..11 were waited for): its slot takes */   \
+      /* row h+3.  vmcnt(0): this wave's earlier DMA (row h+2, a step old) has landed. */                    \
+      C64_STAMP(1)                                                                                           \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+      __builtin_amdgcn_s_barrier();                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      C64_STAMP(2)                                                                                           \
+      stage_x(h + 3);                                                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+    }                                                                                                        \
+    if ((i) == 12) {                                                                                         \
+      /* the parked row's read-back -> stores (POOL: the pool of the parked row pair): straight-line */      \
+      /* code behind the LDS-DMA issue; the group barriers below spread it over the MFMA gaps */             \
+      if constexpr (!POOL) {                                                                                 \
+        deferred_store(prev_off);                                                                            \
+      } else {                                                                                               \
+        C64_NAME4(st[0], st[1], st[2], st[3]);                                                               \
+        pool_code = 0;                                                                                       \
+        pool_word(0); pool_word(1); pool_word(2); pool_word(3);                                              \
+        pool_store(prev_off);                                                                                \
+      }                                                                                                      \
+    }                                                                                                        \
+  }
+    C64_STEP(0) C64_STEP(1) C64_STEP(2) C64_STEP(3) C64_STEP(4) C64_STEP(5) C64_STEP(6) C64_STEP(7) C64_STEP(8)
+    C64_STEP(9) C64_STEP(10) C64_STEP(11) C64_STEP(12) C64_STEP(13) C64_STEP(14) C64_STEP(15) C64_STEP(16)
+    C64_STEP(17) C64_STEP(18) C64_STEP(19) C64_STEP(20) C64_STEP(21) C64_STEP(22) C64_STEP(23) C64_STEP(24)
+    C64_STEP(25) C64_STEP(26) C64_STEP(27) C64_STEP(28) C64_STEP(29) C64_STEP(30) C64_STEP(31) C64_STEP(32)
+    C64_STEP(33) C64_STEP(34) C64_STEP(35)
+    // scheduling region = barrier .. end of the chain: one MFMA, then a few VALU / VMEM of the
+    // deferred epilogue and of the read addresses, 24 times
+#pragma unroll
+    for (int g = 0; g < 24; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, POOL ? 8 : (MASK ? 8 : 5), 0);
+      __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+    }
+#undef C64_STEP
+#undef C64_YOUNG
+#undef C64_RD
+    C64_STAMP(3)
+    // ---- the finished row: (+ earlier partial sums) -> bf16 -> ReLU -> parked in the row buffer
+    if (!POOL && p.acc_src && (w0 + l31) < p.W) {
+      // two-pass 128-channel reduction (opt-in): register r = cout 8*(r>>2) + 4*hb + (r&3) of pixel l31
       const char* ap = p.acc_src + ((img_px + (size_t)h * p.W + w0 + l31) * O + wave * 32 + 4 * hb) * 2;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pv[q] = *(const u32x2_t*)(ap + q * 16);
-    }
-    f32x16_t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // tap t+1's four fragment reads are issued before tap t's four MFMAs; asm reads with counted
-    // waits (hipcc's own placement waited lgkmcnt(0) at every second tap)
-    u32x4_t xf[2][4];
-    const unsigned lx0 = lds_addr(lX);
-#define C64_RD(buf, t)                                                                          \
-  {                                                                                             \
-    const unsigned s_ = lx0 + ((h + (t) / 3) & 3) * X_SLOT;                                     \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) DTP_DSR128(xf[buf][k], s_ + xoff[(t) % 3][k]); \
-  }
-    __builtin_amdgcn_sched_barrier(0);
-    C64_RD(0, 0)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (t + 1 < 9) {
-        C64_RD((t + 1) & 1, t + 1)
-        DTP_LGKM_WAIT4(4, xf[t & 1][0], xf[t & 1][1], xf[t & 1][2], xf[t & 1][3]);
-      } else {
-        DTP_LGKM_WAIT4(0, xf[t & 1][0], xf[t & 1][1], xf[t & 1][2], xf[t & 1][3]);
+      for (int q = 0; q < 4; ++q) {
+        const u32x2_t pv = *(const u32x2_t*)(ap + q * 16);
+        acc[q * 4 + 0] += __uint_as_float(pv[0] << 16);
+        acc[q * 4 + 1] += __uint_as_float(pv[0] & 0xFFFF0000u);
+        acc[q * 4 + 2] += __uint_as_float(pv[1] << 16);
+        acc[q * 4 + 3] += __uint_as_float(pv[1] & 0xFFFF0000u);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][k], __builtin_bit_cast(bf16x8_t, xf[t & 1][k]), acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
     }
-#undef C64_RD
     {
-      // bias: register 4q + e holds cout 8q + 4hb + e -> one 16-byte LDS read per q
+      typedef short s16x2_t __attribute__((ext_vector_type(2)));
+      const bool relu = POOL || p.relu;
+      const unsigned buf = POOL ? (unsigned)((h - h0) & 1) * 2048u : 0u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4_t b4 = *(const f32x4_t*)(lBias + wave * 32 + 8 * q + 4 * hb);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[q * 4 + e] += b4[e];
+        uint32_t lo = pack_bf16x2(acc[q * 4 + 0], acc[q * 4 + 1]), hi = pack_bf16x2(acc[q * 4 + 2], acc[q * 4 + 3]);
+        if (relu) {   // round(relu(x)) == relu(round(x)): packed signed-16-bit max on the bf16 bit patterns
+          lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, lo), (s16x2_t){0, 0}));
+          hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, hi), (s16x2_t){0, 0}));
+        }
+        const u32x2_t pk = {lo, hi};
+        C64_DSW64(wr_a + buf + ((q ^ wr_sw) << 4), pk);
       }
     }
-    if (!POOL && p.acc_src) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc[q * 4 + 0] += __uint_as_float(pv[q][0] << 16);
-        acc[q * 4 + 1] += __uint_as_float(pv[q][0] & 0xFFFF0000u);
-        acc[q * 4 + 2] += __uint_as_float(pv[q][1] << 16);
-        acc[q * 4 + 3] += __uint_as_float(pv[q][1] & 0xFFFF0000u);
-      }
-    }
-    if constexpr (POOL) {
-      // ---- fused ReLU + 2x2/s2 max-pool: the full-resolution output is never written.  Lane =
-      // (pixel l31, hb); horizontal partner = lane ^ 1; the top row of each window waits in
-      // registers for the bottom row.  Tie rule = torch's (first maximum in (0,0),(0,1),(1,0),(1,1)
-      // order), evaluated on the bf16-rounded, ReLU'd values like the stand-alone pool kernel.
-      float hm[16];
-      uint32_t ha = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = bf16_to_f32(f32_to_bf16(fmaxf(acc[r], 0.f)));
-        const float o = __shfl_xor(v, 1);
-        const bool right = o > v;                      // meaningful on even-pixel lanes
-        hm[r] = right ? o : v;
-        ha |= (right ? 1u : 0u) << (2 * r);
-      }
-      if (((h - h0) & 1) == 0) {
-        // park the top row in this lane's private LDS strip (bf16 pairs): keeps the kernel at two
-        // waves per SIMD (the filter slice already owns 144 VGPRs)
-        u32x4_t t0, t1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          t0[e] = pack_bf16x2(hm[2 * e], hm[2 * e + 1]);
-          t1[e] = pack_bf16x2(hm[8 + 2 * e], hm[8 + 2 * e + 1]);
-        }
-        *(u32x4_t*)(myT) = t0;
-        *(u32x4_t*)(myT + 16) = t1;
-        top_a = ha;
-      } else {
-        float top_m[16];
-        {
-          const u32x4_t t0 = *(const u32x4_t*)(myT), t1 = *(const u32x4_t*)(myT + 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            top_m[2 * e] = __uint_as_float(t0[e] << 16);
-            top_m[2 * e + 1] = __uint_as_float(t0[e] & 0xFFFF0000u);
-            top_m[8 + 2 * e] = __uint_as_float(t1[e] << 16);
-            top_m[8 + 2 * e + 1] = __uint_as_float(t1[e] & 0xFFFF0000u);
-          }
-        }
-        uint32_t hc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float m4[4];
-          uint32_t nib = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = q * 4 + e;
-            float m = top_m[r];
-            uint32_t arg = (top_a >> (2 * r)) & 1u;
-            if (hm[r] > m) { m = hm[r]; arg = 2u + ((ha >> (2 * r)) & 1u); }
-            m4[e] = m;
-            nib |= (arg | (m > 0.f ? 4u : 0u)) << (4 * e);
-          }
-          hc[q] = nib;                                 // channels 8q + 4hb .. +3 of this wave's 32
-          u32x2_t pk;
-          pk[0] = pack_bf16x2(m4[0], m4[1]);
-          pk[1] = pack_bf16x2(m4[2], m4[3]);
-          const int pp = l31 >> 1;                     // pooled pixel within the strip (even lanes)
-          const int slot8 = (2 * q + hb) ^ (pp & 7);
-          if ((l31 & 1) == 0) *(u32x2_t*)(myO + pp * 64 + slot8 * 8) = pk;
-        }
-        // codes: lane hb = 0 holds nibbles 0-3 of each 8-channel group, its partner (lane + 32) 4-7
-        const uint32_t c01 = hc[0] | (hc[1] << 16), c23 = hc[2] | (hc[3] << 16);
-        const uint32_t o01 = __shfl_xor(c01, 32), o23 = __shfl_xor(c23, 32);
-        __builtin_amdgcn_wave_barrier();
-        const int OHp = p.H >> 1, OWp = p.W >> 1;
-        const size_t prow = ((size_t)n * OHp + (h >> 1)) * OWp + (w0 >> 1);
-        {
-          const int px = lane >> 2, c16 = lane & 3;    // 16 pooled pixels x 4 chunks of 16 B
-          const int x7 = px & 7;
-          u32x4_t v;
-          const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
-          const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
-          v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-          if ((w0 + 2 * px) < p.W) *(u32x4_t*)(p.out + ((prow + px) * O + wave * 32 + c16 * 8) * 2) = v;
-        }
-        if (hb == 0 && (l31 & 1) == 0 && (w0 + l31) < p.W) {
-          u32x4_t cw;
-          cw[0] = (c01 & 0xFFFFu) | (o01 << 16);
-          cw[1] = (c01 >> 16) | (o01 & 0xFFFF0000u);
-          cw[2] = (c23 & 0xFFFFu) | (o23 << 16);
-          cw[3] = (c23 >> 16) | (o23 & 0xFFFF0000u);
-          *(u32x4_t*)(p.codes + (prow + (l31 >> 1)) * (O / 8) + wave * 4) = cw;
-        }
-      }
-    } else {
-      // ---- epilogue: (relu) -> bf16 -> per-wave LDS shuffle -> 16-byte row-segment stores
-  #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v[4];
-  #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = acc[q * 4 + e];
-          if (p.relu) v[e] = fmaxf(v[e], 0.f);
-        }
-        u32x2_t pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
-        const int slot8 = (2 * q + hb) ^ (l31 & 7);            // 8-byte slot = couts 8q + 4hb .. +3
-        *(u32x2_t*)(myO + l31 * 64 + slot8 * 8) = pk;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const size_t row_px = img_px + (size_t)h * p.W + w0;
-  #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int id = lane + 64 * r;                           // 128 chunks of 16 B: (px, c16)
-        const int px = id >> 2, c16 = id & 3;
-        const int x7 = px & 7;
-        u32x4_t v;
-        const u32x2_t lo = *(const u32x2_t*)(myO + px * 64 + (((2 * c16) ^ x7) << 3));
-        const u32x2_t hi = *(const u32x2_t*)(myO + px * 64 + (((2 * c16 + 1) ^ x7) << 3));
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-        if ((w0 + px) < p.W) {
-          const size_t goff = ((row_px + px) * O + wave * 32 + c16 * 8) * 2;
-          if (p.mask_src) {
-            const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
-  #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const uint32_t mw = mk[e], vw = v[e];
-              const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
-              const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
-              const float a = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
-              const float b = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
-              v[e] = pack_bf16x2(a, b);
-            }
-          }
-          *(u32x4_t*)(p.out + goff) = v;
-          if (p.bits_out) {
-            uint32_t b = 0;
-  #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const uint32_t vw = v[e];
-              b |= (uint32_t)(((vw & 0x8000u) == 0) && ((vw & 0x7FFFu) != 0)) << (2 * e);
-              b |= (uint32_t)(((vw & 0x80000000u) == 0) && ((vw & 0x7FFF0000u) != 0)) << (2 * e + 1);
-            }
-            p.bits_out[goff >> 4] = (unsigned char)b;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
+    C64_STAMP(4)
   }
-  (void)px_ok;
+  // ---- flush the last parked row / row pair
+  {
+    const unsigned last_off = (unsigned)(POOL ? (h1 - 1) >> 1 : h1 - 1) * o_row_bytes;
+    deferred_reads(last_off);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!POOL) {
+      deferred_store(last_off);
+    } else {
+      C64_NAME4(st[0], st[1], st[2], st[3]);
+      pool_code = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pool_word(j);
+      pool_store(last_off);
+    }
+  }
 }
 
 // X [N,H,W,64] bf16, Wt [O][576] bf16 -> out [N,H,W,O] bf16 (O = 64 or 128)
@@ -326,6 +389,8 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
   p.out = (char*)out; p.zero_page = (const char*)zero_page;
   p.ldx = ldx; p.acc_src = (const char*)acc_src;
   p.N = N; p.H = H; p.W = W; p.relu = relu; p.mask_scale = mask_scale;
+  p.stamps = nullptr;
+  if (const char* e = std::getenv("DTP_C64_STAMPS")) p.stamps = (unsigned long long*)std::strtoull(e, nullptr, 0);
   p.S = (W + 31) / 32;
   const long units = (long)N * p.S;
   // row chunks: enough workgroups to fill the chip several times over, >= 16 rows each so the
@@ -348,14 +413,18 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
     }
   }
   const long grid2 = units * p.RC;
+  static const int lds_pad = std::getenv("DTP_C64_LDS_PAD") ? std::atoi(std::getenv("DTP_C64_LDS_PAD")) : 0;   // DEBUG: occupancy experiments
+  const bool mask = mask_src != nullptr;
   if (O == 64) {
-    constexpr int lds = 4 * 40 * 128 + 2 * 2048 + 128 * 32 + 64 * 4;
-    if (codes) hipLaunchKernelGGL((conv_c64_kernel<64, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
-    else hipLaunchKernelGGL((conv_c64_kernel<64, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
+    const int lds = 4 * 6144 + 2 * 4096 + 64 * 4 + lds_pad;
+    if (codes) hipLaunchKernelGGL((conv_c64_kernel<64, true, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
+    else if (mask) hipLaunchKernelGGL((conv_c64_kernel<64, false, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<64, false, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
   } else {
-    constexpr int lds = 4 * 40 * 128 + 4 * 2048 + 256 * 32 + 128 * 4;
-    if (codes) hipLaunchKernelGGL((conv_c64_kernel<128, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((conv_c64_kernel<128, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
+    const int lds = 4 * 8192 + 4 * 4096 + 128 * 4 + lds_pad;
+    if (codes) hipLaunchKernelGGL((conv_c64_kernel<128, true, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
+    else if (mask) hipLaunchKernelGGL((conv_c64_kernel<128, false, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<128, false, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
   }
   return DTP_CHECK_LAUNCH();
 }
