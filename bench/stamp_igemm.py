@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BF16 = torch.bfloat16
-N_IMG, HW, C, Co = 256, 56, int(os.environ.get("C", "256")), 256
+N_IMG, HW, C, Co = int(os.environ.get("N", "256")), 56, int(os.environ.get("C", "256")), 256
 M = N_IMG * HW * HW
 tiles = (M + 255) // 256 * ((Co + 255) // 256)
 stamps = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")

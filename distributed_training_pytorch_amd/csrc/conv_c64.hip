@@ -195,15 +195,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
         }
       }
       __builtin_amdgcn_raw_buffer_store_b128(v, o_rs, (int)off, 0, 0);
-      // (x > 0) per bf16 half as clamp((int16)x, 0, 1): two packed ops per word, then 2 bits per word
-      typedef short s16x2_t __attribute__((ext_vector_type(2)));
-      uint32_t b = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const s16x2_t c = __builtin_elementwise_max(__builtin_elementwise_min(__builtin_bit_cast(s16x2_t, v[e]), (s16x2_t){1, 1}), (s16x2_t){0, 0});
-        const uint32_t cw = __builtin_bit_cast(uint32_t, c);
-        b |= ((cw | (cw >> 15)) & 3u) << (2 * e);
-      }
+      const uint32_t b = bf16x2_pos_bits(v[0]) | (bf16x2_pos_bits(v[1]) << 2) | (bf16x2_pos_bits(v[2]) << 4) | (bf16x2_pos_bits(v[3]) << 6);
       __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, b_rs, (int)(off >> 4), 0, 0);
     }
   };

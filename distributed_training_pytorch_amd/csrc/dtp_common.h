@@ -31,6 +31,15 @@ DTP_DEVINL uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16v2_t));
 }
 
+// (x > 0) of the two bf16 halves of a word as bits 0 (low half) and 1 (high half).  Plain scalar
+// arithmetic on purpose: a packed-int16 clamp over `v[e]` in an unrolled loop was folded by hipcc
+// into four copies of word 0's bits (caught by test_relu_bitmask_roundtrip).
+DTP_DEVINL uint32_t bf16x2_pos_bits(uint32_t w) {
+  const uint32_t lo = ((w & 0xFFFFu) - 1u) < 0x7FFFu ? 1u : 0u;      // 0x0001 .. 0x7FFF
+  const uint32_t hi = (int32_t)w >= 0x10000 ? 2u : 0u;               // sign clear, high half non-zero
+  return lo | hi;
+}
+
 // Async global->LDS copy of 16 bytes per lane. LDS destination is wave-uniform base + lane*16.
 DTP_DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -507,7 +507,39 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     return;
   }
 
-  __syncthreads();   // all waves finished reading the staging buffers
+  // ---- store-loop geometry and the 1-bit ReLU masks of this lane's 16-byte chunks: the byte loads
+  // are issued here, before the C image is written, so their latency hides under that phase
+  constexpr int CPR = BN / 8;                 // 16-B chunks per C row
+  constexpr int TOTAL = BM * CPR;
+  // T % CPR == 0: a lane keeps its 8-column chunk q and walks rows pl0, pl0 + G, ...
+  constexpr int G = T / CPR;
+  constexpr int ITER = TOTAL / T;
+  static_assert(T % CPR == 0 && TOTAL % T == 0, "store loop geometry");
+  const int q = tid % CPR, pl0 = tid / CPR;
+  const int n = n0 + q * 8;
+  const bool n_ok = n < p.Ncols;
+  // The store loop used to be one pass per row with the kernel-uniform feature tests (mask kind,
+  // 1-bit masks out, column sums) and the row / column tail tests inside it: ~270 instructions and
+  // one exposed LDS read latency per 16-byte store, 6,500 cycles per 256x256 tile whether 49 or
+  // 256 CUs were storing (in-kernel stamps: issue-bound, not a write burst).  Now: four LDS reads at
+  // a time, the optional masking as separate unrolled passes, then four stores back to back through
+  // a buffer descriptor over this tile's valid rows (row tail = out of range = dropped by the
+  // hardware, column tail = out-of-range offset), row stride in the scalar offset: 3,000 cycles.
+  const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+  const long tile_bytes = (long)rows_valid * p.ldo * 2;
+  const unsigned voff = n_ok ? (unsigned)((pl0 * p.ldo + n) * 2) : DTP_OOB_OFF;
+  const int row_step = G * p.ldo * 2;         // bytes between two rows of this lane (kernel-uniform)
+  uint32_t mb[ITER];
+  if (p.mask_bits) {
+    const __amdgpu_buffer_rsrc_t mb_rs = make_rsrc(p.mask_bits + (((size_t)m0 * p.ldo) >> 3), tile_bytes >> 4);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+      mb[it] = __builtin_amdgcn_raw_buffer_load_b8(mb_rs, (int)(n_ok ? voff >> 4 : DTP_OOB_OFF), it * (row_step >> 4), 0);
+  }
+  // raw barriers: hipcc's __syncthreads() waits vmcnt(0) first, which would expose the mask loads above
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // all waves finished reading the staging buffers
+  __builtin_amdgcn_sched_barrier(0);
   DTP_STAMP(5)
   {
     const float keep_scale = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
@@ -576,87 +608,85 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       else body(std::false_type{});
     }
   }
-  __syncthreads();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();   // C image complete
+  __builtin_amdgcn_sched_barrier(0);
   DTP_STAMP(6)
   {
-    constexpr int CPR = BN / 8;                 // 16-B chunks per C row
-    constexpr int TOTAL = BM * CPR;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // T % CPR == 0: a lane keeps its 8-column chunk q and walks rows pl0, pl0 + G, ...
-    constexpr int G = T / CPR;
-    constexpr int ITER = TOTAL / T;
-    static_assert(T % CPR == 0 && TOTAL % T == 0, "store loop geometry");
-    const int q = tid % CPR, pl0 = tid / CPR;
-    const int n = n0 + q * 8;
-    const bool n_ok = n < p.Ncols;
-    // 1-bit masks of ALL this lane's chunks in one batch of byte loads, issued before the first
-    // LDS read: one exposed load latency per tile instead of one per row (the masked store loop
-    // was 10-12 us of a 256x256 data-gradient tile, in-kernel stamps)
-    uint32_t mb[ITER];
+    const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + (size_t)m0 * p.ldo * 2, tile_bytes);
+    const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
+    constexpr int CH = ITER < 4 ? ITER : 4;     // rows per lane and pass: 4 LDS reads in flight, 4 stores back to back
+    static_assert(ITER % CH == 0, "store loop chunking");
+#pragma unroll
+    for (int c0 = 0; c0 < ITER; c0 += CH) {
+    u32x4_t v[CH];
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      const int pl = pl0 + (c0 + it) * G;
+      v[it] = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
+    }
     if (p.mask_bits) {
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int m = m0 + pl0 + it * G;
-        mb[it] = (n_ok && m < p.M) ? p.mask_bits[((size_t)m * p.ldo + n) >> 3] : 0u;
-      }
-    }
-    const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int pl = pl0 + it * G;
-      const int m = m0 + pl;
-      if (!n_ok || m >= p.M) continue;
-      u32x4_t v = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
-      const size_t goff = ((size_t)m * p.ldo + n) * 2;
-      if (p.mask_bits) {
+      for (int it = 0; it < CH; ++it) {
         if (unit_scale) {
           // keep / clear each bf16 by AND with a mask built from two sign-extended bit extracts
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int s0 = (int)(mb[it] << (31 - 2 * e)) >> 31;        // bit 2e   -> 0 / ~0
-            const int s1 = (int)(mb[it] << (30 - 2 * e)) >> 31;        // bit 2e+1 -> 0 / ~0
-            v[e] &= ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 & 0xFFFF0000u);
+            const int s0 = (int)(mb[c0 + it] << (31 - 2 * e)) >> 31;        // bit 2e   -> 0 / ~0
+            const int s1 = (int)(mb[c0 + it] << (30 - 2 * e)) >> 31;        // bit 2e+1 -> 0 / ~0
+            v[it][e] &= ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 & 0xFFFF0000u);
           }
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const uint32_t vw = v[e];
-            float lo = ((mb[it] >> (2 * e)) & 1u) ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
-            float hi = ((mb[it] >> (2 * e + 1)) & 1u) ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
-            v[e] = pack_bf16x2(lo, hi);
+            const uint32_t vw = v[it][e];
+            float lo = ((mb[c0 + it] >> (2 * e)) & 1u) ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
+            float hi = ((mb[c0 + it] >> (2 * e + 1)) & 1u) ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
+            v[it][e] = pack_bf16x2(lo, hi);
           }
         }
-      } else if (p.mask_src) {
-        const u32x4_t mk = *(const u32x4_t*)(p.mask_src + goff);
+      }
+    } else if (p.mask_src) {
+      const __amdgpu_buffer_rsrc_t ms_rs = make_rsrc(p.mask_src + (size_t)m0 * p.ldo * 2, tile_bytes);
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const u32x4_t mk = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(ms_rs, (int)voff, (c0 + it) * row_step, 0));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const uint32_t mw = mk[e], vw = v[e];
+          const uint32_t mw = mk[e], vw = v[it][e];
           // bf16 > 0  <=>  sign clear and magnitude non-zero
           const bool lo_pos = ((mw & 0x8000u) == 0) && ((mw & 0x7FFFu) != 0);
           const bool hi_pos = ((mw & 0x80000000u) == 0) && ((mw & 0x7FFF0000u) != 0);
           float lo = lo_pos ? bf16_to_f32((bf16_t)(vw & 0xFFFFu)) * p.mask_scale : 0.f;
           float hi = hi_pos ? bf16_to_f32((bf16_t)(vw >> 16)) * p.mask_scale : 0.f;
-          v[e] = pack_bf16x2(lo, hi);
+          v[it][e] = pack_bf16x2(lo, hi);
         }
       }
-      *(u32x4_t*)(p.out + goff) = v;
-      if (p.bits_out) {
-        uint32_t b = 0;
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t vw = v[e];
-          b |= (uint32_t)(((vw & 0x8000u) == 0) && ((vw & 0x7FFFu) != 0)) << (2 * e);
-          b |= (uint32_t)(((vw & 0x80000000u) == 0) && ((vw & 0x7FFF0000u) != 0)) << (2 * e + 1);
-        }
-        p.bits_out[goff >> 4] = (unsigned char)b;
-      }
-      if (p.colsum_part) {
+    for (int it = 0; it < CH; ++it) __builtin_amdgcn_raw_buffer_store_b128(v[it], o_rs, (int)voff, (c0 + it) * row_step, 0);
+    if (p.bits_out) {
+      const __amdgpu_buffer_rsrc_t bo_rs = make_rsrc(p.bits_out + (((size_t)m0 * p.ldo) >> 3), tile_bytes >> 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          cs[2 * e] += __uint_as_float(v[e] << 16);
-          cs[2 * e + 1] += __uint_as_float(v[e] & 0xFFFF0000u);
+      for (int it = 0; it < CH; ++it) {
+        const u32x4_t x = v[it];
+        const uint32_t b = bf16x2_pos_bits(x[0]) | (bf16x2_pos_bits(x[1]) << 2) | (bf16x2_pos_bits(x[2]) << 4) | (bf16x2_pos_bits(x[3]) << 6);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, bo_rs, (int)(n_ok ? voff >> 4 : DTP_OOB_OFF), (c0 + it) * (row_step >> 4), 0);
+      }
+    }
+    if (p.colsum_part) {
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        if (n_ok && pl0 + (c0 + it) * G < rows_valid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            cs[2 * e] += __uint_as_float(v[it][e] << 16);
+            cs[2 * e + 1] += __uint_as_float(v[it][e] & 0xFFFF0000u);
+          }
         }
       }
+    }
     }
     DTP_STAMP(4)
     if (p.colsum_part) {   // kernel-uniform
