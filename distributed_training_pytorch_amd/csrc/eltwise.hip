@@ -298,8 +298,8 @@ __global__ void amax_pass1_kernel(const T* __restrict__ x, size_t n, float* __re
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-// scale_out[0] = dequantisation factor (amax / 448, or 1 for an all-zero tensor)
-__global__ void amax_pass2_kernel(const float* __restrict__ part, int nb, float* __restrict__ scale_out) {
+// scale_out[0] = dequantisation factor (amax / qmax — 448 for e4m3, 57344 for e5m2 — or 1 for an all-zero tensor)
+__global__ void amax_pass2_kernel(const float* __restrict__ part, int nb, float* __restrict__ scale_out, float qmax) {
   __shared__ float red[256];
   float m = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) m = fmaxf(m, part[i]);
@@ -309,44 +309,56 @@ __global__ void amax_pass2_kernel(const float* __restrict__ part, int nb, float*
     if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) scale_out[0] = red[0] > 0.f ? red[0] * (1.f / 448.f) : 1.f;
+  if (threadIdx.x == 0) scale_out[0] = red[0] > 0.f ? red[0] / qmax : 1.f;
 }
 
-template <typename T>
+// E5M2: gradients ("bf8": 2 mantissa bits, the range of fp16) — v_cvt_pk_bf8_f32; else OCP e4m3
+template <typename T, bool E5M2>
 __global__ void quant_fp8_kernel(const T* __restrict__ x, size_t n4, const float* __restrict__ scale,
                                  uint32_t* __restrict__ out) {
-  const float inv = 1.f / scale[0];
+  // true division, not a multiplication by the reciprocal: amax/qmax scales put ~1 % of bf16 inputs
+  // EXACTLY on a rounding tie of the 2-3 mantissa bits, and x * (1/s) breaks those ties the other way
+  const float sc = scale[0];
+  constexpr float QMAX = E5M2 ? 57344.f : 448.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float f = load_as_f32<T>(x + 4 * i + e) * inv;
-      v[e] = fminf(fmaxf(f, -448.f), 448.f);
+      float f = __fdiv_rn(load_as_f32<T>(x + 4 * i + e), sc);
+      v[e] = fminf(fmaxf(f, -QMAX), QMAX);
     }
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    int w;
+    if (E5M2) {
+      w = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+      w = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], w, true);
+    } else {
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+    }
     out[i] = (uint32_t)w;
   }
 }
 
-// x: n elements of f32 (kind 0) or bf16 (kind 1), n % 4 == 0 -> out: n bytes of e4m3; scale_out[0] = dequant factor;
-// workspace: >= 1024 floats
+// x: n elements of f32 (kind bit 0 clear) or bf16 (bit 0 set), n % 4 == 0 -> out: n bytes of e4m3 (kind bit 1
+// clear) or e5m2 (bit 1 set); scale_out[0] = dequant factor; workspace: >= 1024 floats
 extern "C" int dtp_quant_fp8(const void* x, int kind, size_t n, void* out, float* scale_out, float* workspace,
                              hipStream_t s) {
-  if (n == 0 || (n & 3) || (kind != 0 && kind != 1)) return -10;
+  if (n == 0 || (n & 3) || kind < 0 || kind > 3) return -10;
   int nb = (int)((n + 256 * 16 - 1) / (256 * 16));
   if (nb > 1024) nb = 1024;
   const int qb = grid_for(n / 4, 256, 4096);
-  if (kind == 0) {
+  const bool e5m2 = (kind & 2) != 0;
+  const float qmax = e5m2 ? 57344.f : 448.f;
+  if ((kind & 1) == 0) {
     hipLaunchKernelGGL(amax_pass1_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, n, workspace);
-    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out);
-    hipLaunchKernelGGL(quant_fp8_kernel<float>, dim3(qb), dim3(256), 0, s, (const float*)x, n / 4, scale_out,
-                       (uint32_t*)out);
+    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out, qmax);
+    if (e5m2) hipLaunchKernelGGL((quant_fp8_kernel<float, true>), dim3(qb), dim3(256), 0, s, (const float*)x, n / 4, scale_out, (uint32_t*)out);
+    else hipLaunchKernelGGL((quant_fp8_kernel<float, false>), dim3(qb), dim3(256), 0, s, (const float*)x, n / 4, scale_out, (uint32_t*)out);
   } else {
     hipLaunchKernelGGL(amax_pass1_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, n, workspace);
-    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out);
-    hipLaunchKernelGGL(quant_fp8_kernel<bf16_t>, dim3(qb), dim3(256), 0, s, (const bf16_t*)x, n / 4, scale_out,
-                       (uint32_t*)out);
+    hipLaunchKernelGGL(amax_pass2_kernel, dim3(1), dim3(256), 0, s, workspace, nb, scale_out, qmax);
+    if (e5m2) hipLaunchKernelGGL((quant_fp8_kernel<bf16_t, true>), dim3(qb), dim3(256), 0, s, (const bf16_t*)x, n / 4, scale_out, (uint32_t*)out);
+    else hipLaunchKernelGGL((quant_fp8_kernel<bf16_t, false>), dim3(qb), dim3(256), 0, s, (const bf16_t*)x, n / 4, scale_out, (uint32_t*)out);
   }
   return DTP_CHECK_LAUNCH();
 }

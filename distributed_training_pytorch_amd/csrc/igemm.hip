@@ -45,6 +45,7 @@ struct IgemmParams {
   float mask_scale;
   float drop_p;
   unsigned long long seed;
+  int a_bf8;                            // fp8 kernels: the A rows (x) are e5m2, not e4m3 (gradients)
   const float* dq_a;                    // optional device scalars: accumulator *= *dq_a * *dq_b (fp8 dequant)
   const float* dq_b;
   const unsigned long long* seed_ptr;   // optional device-resident base seed (hipGraph replay): seed += *seed_ptr
@@ -58,13 +59,19 @@ struct IgemmParams {
 // 16x16x32 MFMA step on one 16-byte fragment pair.  FP8: the 16 bytes are 16 OCP e4m3 values, fed
 // to two v_mfma_f32_16x16x32_fp8_fp8 (8 bytes per lane each); A and B use the same lane->k map, so
 // the k order inside the 128-element chunk is irrelevant to the dot product.
-template <bool FP8>
+// MODE 0: bf16; 1: both operands e4m3; 2: x (the activation / gradient rows) in e5m2 ("bf8"), w in e4m3
+template <int MODE>
 DTP_DEVINL f32x4_t mma16(const bf16x8_t& w, const bf16x8_t& x, f32x4_t c) {
-  if constexpr (FP8) {
+  if constexpr (MODE != 0) {
     typedef long l2_t __attribute__((ext_vector_type(2)));
     const l2_t wl = __builtin_bit_cast(l2_t, w), xl = __builtin_bit_cast(l2_t, x);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], xl[0], c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], xl[1], c, 0, 0, 0);
+    if constexpr (MODE == 1) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], xl[0], c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], xl[1], c, 0, 0, 0);
+    } else {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wl[0], xl[0], c, 0, 0, 0);
+      return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(wl[1], xl[1], c, 0, 0, 0);
+    }
   } else {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
   }
@@ -200,7 +207,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  auto compute = [&](int buf) {
+  auto compute_m = [&](int buf, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
     const char* base = smem + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -214,8 +222,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = mma16<FP8>(wf[j], xf[i], acc[i][j]);
+          acc[i][j] = mma16<MODE>(wf[j], xf[i], acc[i][j]);
     }
+  };
+  auto compute = [&](int buf) {
+    if constexpr (!FP8) compute_m(buf, std::integral_constant<int, 0>{});
+    else if (p.a_bf8) compute_m(buf, std::integral_constant<int, 2>{});      // kernel-uniform
+    else compute_m(buf, std::integral_constant<int, 1>{});
   };
 
   // Software-pipelined K-step (PIPE == 1): the wave's tile is cut into sub-steps
@@ -760,7 +773,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
                             const float* dq_a, const float* dq_b, int nsplit, int cfg, hipStream_t stream) {
-  // fp8 (OCP e4m3) operands: A [M][lda], B [Ncols][ldb] bytes, K = C a multiple of 128
+  // fp8 != 0: 8-bit operands, A [M][lda] (fp8 == 1: OCP e4m3, fp8 == 2: e5m2), B [Ncols][ldb] e4m3, bytes; K = C a multiple of 128
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
   if (fp8 && (taps != 1 || (lda & 15) || (ldb & 15))) return -18;
   if (taps != 1 && taps != 9) return -11;
@@ -776,6 +789,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;
   p.seed_ptr = (const unsigned long long*)seed_ptr;
   p.dq_a = dq_a; p.dq_b = dq_b;
+  p.a_bf8 = fp8 == 2;
   static const int k_order_env = std::getenv("DTP_IGEMM_KORDER") ? std::atoi(std::getenv("DTP_IGEMM_KORDER")) : 1;
   p.k_order = k_order_env;
   p.stamps = nullptr;

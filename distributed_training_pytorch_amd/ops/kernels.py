@@ -186,7 +186,7 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
            mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
-           bits_out=None):
+           bits_out=None, fp8_mode=1):
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
@@ -214,7 +214,7 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
                                  ptr(partial), ptr(cs_part),
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
-                                 ptr(seed_ptr), int(fp8), ptr(fp8_scales[0]) if fp8 else None,
+                                 ptr(seed_ptr), int(fp8_mode) if fp8 else 0, ptr(fp8_scales[0]) if fp8 else None,
                                  ptr(fp8_scales[1]) if fp8 else None, nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
@@ -357,15 +357,16 @@ def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, 
                   seed_ptr=seed_ptr)
 
 
-def quant_fp8(x):
-    """Per-tensor OCP e4m3 quantisation on the device: returns (q uint8 tensor shaped like x,
-    scale f32[1]) with x ~= q * scale; amax, scale and conversion never touch the host."""
+def quant_fp8(x, e5m2=False):
+    """Per-tensor 8-bit float quantisation on the device — OCP e4m3 (activations, weights) or
+    e5m2 (``e5m2=True``: gradients) — returns (q uint8 tensor shaped like x, scale f32[1]) with
+    x ~= q * scale; amax, scale and conversion never touch the host."""
     if not x.is_cuda or not x.is_contiguous() or x.dtype not in (torch.float32, BF16) or x.numel() % 4:
         raise ValueError("quant_fp8: contiguous CUDA f32/bf16 tensor with numel % 4 == 0")
     q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     scale = torch.empty(1, dtype=torch.float32, device=x.device)
     ws = workspace.get("amax", 1024, torch.float32, x.device)
-    check(_lib.hip().dtp_quant_fp8(ptr(x), int(x.dtype == BF16), x.numel(), ptr(q), ptr(scale), ptr(ws), stream()),
+    check(_lib.hip().dtp_quant_fp8(ptr(x), int(x.dtype == BF16) | (2 if e5m2 else 0), x.numel(), ptr(q), ptr(scale), ptr(ws), stream()),
           "quant_fp8")
     return q, scale
 
@@ -387,6 +388,25 @@ def linear_fwd_fp8(xq, x_scale, wq, w_scale, bias=None, relu=False, drop_p=0.0, 
     out = torch.empty((M, Nout), dtype=torch.float32 if out_fp32 else BF16, device=xq.device)
     return _igemm(xq, wq, bias, None, out, M, Nout, K, 1, 1, 1, K, K, Nout, out_fp32, relu, 1.0, drop_p, seed,
                   seed_ptr=seed_ptr, fp8_scales=(x_scale, w_scale))
+
+
+def linear_dgrad_fp8(dyq, dy_scale, wtq, wt_scale, mask_src=None, mask_scale=1.0):
+    """dx = (dyq @ wtq.T) * dy_scale * wt_scale [* (mask_src > 0) * mask_scale] on
+    v_mfma_f32_16x16x32_fp8_bf8: dyq [M, ld] uint8 holding e5m2 gradients, wtq [K_in, ld] uint8
+    holding the e4m3 TRANSPOSED weight (``quant_fp8(W.T)``), ld % 128 == 0, f32 accumulation, bf16 out."""
+    for t, name in ((dyq, "dyq"), (wtq, "wtq")):
+        _need(t, torch.uint8, name)
+    M, ld = dyq.shape
+    Kin = wtq.shape[0]
+    if wtq.shape[1] != ld or ld % 128 or Kin % 8:
+        raise ValueError("linear_dgrad_fp8: bad shapes dyq=%s wtq=%s" % (tuple(dyq.shape), tuple(wtq.shape)))
+    if mask_src is not None:
+        _need(mask_src, BF16, "mask_src")
+        if tuple(mask_src.shape) != (M, Kin):
+            raise ValueError("mask_src shape")
+    out = torch.empty((M, Kin), dtype=BF16, device=dyq.device)
+    return _igemm(dyq, wtq, None, mask_src, out, M, Kin, ld, 1, 1, 1, ld, ld, Kin, False, False, mask_scale, 0.0, 0,
+                  fp8_scales=(dy_scale, wt_scale), fp8_mode=2)
 
 
 def linear_dgrad(dy, wt, ld_dy=None, mask_src=None, mask_scale=1.0, out=None):

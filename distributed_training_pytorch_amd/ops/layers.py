@@ -31,6 +31,7 @@ _seed_counter = itertools.count(1)
 OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
 # unmasked linear data gradient without the per-step W^T copy (A/B switch)
 LINEAR_DGRAD_TT = os.environ.get("DTP_LINEAR_DGRAD_TT", "1") == "1"
+FP8_DGRAD = os.environ.get("DTP_FP8_DGRAD", "1") == "1"     # A/B switch: fp8 layers run their data gradient in e5m2 x e4m3
 _side_streams = {}
 # Deferred join (join the side stream only at the end of backward) is OFF by default: it needs
 # record_stream() on every activation the weight-gradient kernels read, which parks those blocks in
@@ -446,8 +447,10 @@ class _LinearFn(torch.autograd.Function):
         arena = _arena_of(layer)
         if layer.fp8 and x.shape[1] % 128 == 0:
             # fp8 (OCP e4m3) forward GEMM, per-tensor scales computed on the device; the weight copy
-            # is re-quantised once per optimizer step (cache keyed on the arena's lp epoch);
-            # backward stays on the bf16 operands
+            # is re-quantised once per optimizer step (cache keyed on the arena's lp epoch).
+            # Backward: the data gradient runs on e5m2 gradients x e4m3 transposed weights (below),
+            # the weight gradient stays on the bf16 operands (reduction over the batch axis: both
+            # operands would need a transposing 8-bit read)
             wq, w_scale = layer._cached("w_fp8", lambda: K.quant_fp8(arena.lp(weight)))
             xq, x_scale = K.quant_fp8(x)
             y = K.linear_fwd_fp8(xq, x_scale, wq, w_scale, bias.detach(), relu=layer.relu, drop_p=drop_p,
@@ -484,7 +487,16 @@ class _LinearFn(torch.autograd.Function):
             K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
         K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
         dx = None
-        if ctx.needs_input_grad[0] and layer._dgrad_without_wt(dy.shape[0]):
+        if ctx.needs_input_grad[0] and layer.fp8 and FP8_DGRAD and ld % 128 == 0:
+            # fp8 data gradient: dY quantised to e5m2 (per-tensor scale, on the device), W^T to e4m3
+            # once per optimizer step; the ReLU/dropout mask of the layer below rides in the epilogue
+            arena.wait_derived()
+            wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
+            wtq, wt_scale = layer._cached("wt_fp8", lambda: K.quant_fp8(wt))
+            dyq, dy_scale = K.quant_fp8(dy, e5m2=True)
+            dx = K.linear_dgrad_fp8(dyq, dy_scale, wtq, wt_scale, mask_src=x if layer.input_is_relu_out else None,
+                                    mask_scale=ctx.in_scale)
+        elif ctx.needs_input_grad[0] and layer._dgrad_without_wt(dy.shape[0]):
             # dX = dY @ W as a "TT" GEMM (reduction axis slow in BOTH operands, csrc/wgrad.hip) over the
             # weight in its native [N_out, K_in] layout: only the small dY is transposed, the 205 MB
             # W^T copy of linear1 is neither built (0.17 ms of HBM traffic per step) nor kept
@@ -504,7 +516,7 @@ class _LinearFn(torch.autograd.Function):
 
 class _LinearDerived(object):
     def derived_builders(self, needs_input_grad=True):
-        if not needs_input_grad or self._dgrad_without_wt(None):
+        if not needs_input_grad or (self._dgrad_without_wt(None) and not (self.fp8 and FP8_DGRAD)):
             return []
         arena = _arena_of(self)
         return [("wt", lambda: K.linear_weight_transpose(arena.lp(self.weight)))]

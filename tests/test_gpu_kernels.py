@@ -509,6 +509,36 @@ def test_fp8_quant_and_linear_forward(shape):
     assert rel < 0.06, rel
 
 
+@pytest.mark.parametrize("shape", [(256, 4096, 4096), (64, 512, 1024), (200, 384, 2048)])
+def test_linear_dgrad_fp8_e5m2(shape):
+    """fp8 data gradient of the classifier (BASELINE.json config 5): dY quantised to e5m2 on the
+    device == torch's float8_e5m2 cast of dY/scale; the e5m2 x e4m3 GEMM (v_mfma_f32_16x16x32_fp8_bf8)
+    == an fp32 matmul of the dequantised operands, with the ReLU mask of the layer below in the
+    epilogue; and against the unquantised gradient the error is the expected few percent."""
+    k = _k()
+    M, Nout, Kin = shape
+    torch.manual_seed(23)
+    dy = _rand(M, Nout, scale=0.02)
+    w = _rand(Nout, Kin, scale=0.02)
+    xmask = _rand(M, Kin)
+    dyq, ds = k.quant_fp8(dy, e5m2=True)
+    assert abs(ds.item() - dy.float().abs().max().item() / 57344.0) < 1e-6 * ds.item() + 1e-12
+    ref_q = (dy.float() / ds).to(torch.float8_e5m2)
+    same = (dyq.view(torch.float8_e5m2).float() == ref_q.float()).float().mean().item()
+    assert same > 0.999, "e5m2 quantisation differs from torch's cast on %.4f%% of elements" % (100 * (1 - same))
+    wt = k.linear_weight_transpose(w)                      # [Kin, Nout]
+    wtq, ws = k.quant_fp8(wt)
+    dyd = dyq.view(torch.float8_e5m2).float() * ds
+    wtd = wtq.view(torch.float8_e4m3fn).float() * ws
+    ref = (dyd @ wtd.t()) * (xmask.float() > 0) * 1.25
+    dx = k.linear_dgrad_fp8(dyq, ds, wtq, ws, mask_src=xmask, mask_scale=1.25)
+    _close(dx, ref, 1e-2, 1e-2 * ref.abs().max().item(), "fp8 dgrad %s" % (shape,))
+    dx0 = k.linear_dgrad_fp8(dyq, ds, wtq, ws)
+    full = dy.float() @ w.float()
+    rel = (dx0.float() - full).norm().item() / (full.norm().item() + 1e-12)
+    assert rel < 0.12, rel
+
+
 @pytest.mark.parametrize("cfg", [8, 9])
 @pytest.mark.parametrize("shape", [(2, 28, 28, 512, 512), (3, 7, 9, 256, 512), (1, 56, 56, 256, 256),
                                    (70, 4, 4, 256, 256), (2, 224, 9, 128, 384)])
