@@ -16,7 +16,16 @@ What is frozen at capture and how it is kept correct on replay:
   * the bf16 working copy of the weights: written by the captured fused optimizer; a
     ``load_state_dict`` / external parameter edit is detected through the parameters' version
     counters and triggers a re-capture.
-Gradient all-reduce is not captured in this version: with world size > 1 the step runs eagerly.
+Data-parallel runs: the step is captured INCLUDING the gradient all-reduce when the reducer runs on
+the native RCCL transport (``BucketedReducer.graph_capturable``): its C++ scheduler forks the
+communication stream into the capture with an event record / wait pair per bucket and joins it at the
+end of backward, RCCL's collectives are recorded as kernel nodes, and a replay is one launch per rank.
+All ranks capture at the same step (same warm-up count, same hyper-parameter key), so the collective
+sequence stays matched.  Capture uses ``capture_error_mode="thread_local"``: RCCL's proxy thread makes
+HIP calls of its own while this thread records.  With the torch process-group transport, the sharded
+optimizer or gloo the step stays eager.  Verified on one GPU (world-size-1 RCCL communicator: eager ==
+graph bit for bit, tests/test_gpu_model.py); multi-GPU replays are exercised by the driver's runs only
+when ``--hip-graph`` is passed — it is opt-in.
 """
 import torch
 
@@ -35,9 +44,11 @@ class GraphedTrainStep(object):
         self._key = None
         self.replays = 0
         self.captures = 0
-        world = getattr(getattr(model, "reducer", None), "world", 1)
-        self.enabled = (bool(enabled) and torch.cuda.is_available() and self.arena is not None and world == 1
-                        and getattr(optimizer, "graph_safe", False))
+        reducer = getattr(model, "reducer", None) or getattr(self.arena, "reducer", None)
+        world = getattr(reducer, "world", 1)
+        self.distributed = reducer is not None and bool(getattr(reducer, "graph_capturable", False))
+        self.enabled = (bool(enabled) and torch.cuda.is_available() and self.arena is not None
+                        and (world == 1 or self.distributed) and getattr(optimizer, "graph_safe", False))
         self._seed = None
         self._eager_left = 0
 
@@ -70,7 +81,8 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         steps_before = getattr(self.optimizer, "_steps", None)
-        with torch.cuda.graph(g):
+        kw = dict(capture_error_mode="thread_local") if self.distributed else {}
+        with torch.cuda.graph(g, **kw):
             self._seed.add_(self._SEED_STEP)
             self.loss_static = self._eager(self.x_static, self.y_static)
         if steps_before is not None:       # capture ran the Python of step() once without executing it

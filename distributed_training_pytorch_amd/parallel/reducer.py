@@ -444,7 +444,9 @@ class BucketedReducer(object):
         self._cb_queued = False
         if self._core is not None:
             ev0 = ev1 = None
-            if self.require_sync and self.measure_exposed and self.world > 1:
+            # (no timing events inside a hipGraph capture: the replayed graph has no host side)
+            if self.require_sync and self.measure_exposed and self.world > 1 \
+                    and not torch.cuda.is_current_stream_capturing():
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             if self.sharded and self.require_sync:
@@ -526,6 +528,16 @@ class BucketedReducer(object):
                 keep.append((e0, e1))
         self._exposed_pairs = keep
         return self._exposed_ms
+
+    @property
+    def graph_capturable(self):
+        """True when a whole training step INCLUDING the gradient reduction can be recorded into a
+        hipGraph (engine/graph.py): bucket counting, launch and the end-of-backward hand-back run in
+        the C++ scheduler on plain HIP streams / events — an event record on the capturing compute
+        stream plus a wait on the communication stream forks that stream into the capture, the
+        hand-back joins it — and RCCL records its collective kernels like any other launch.  The
+        sharded-optimizer mode keeps per-pass host state (step constants) and is not captured."""
+        return self._core is not None and not self.sharded
 
     def finalize_now(self):
         """Explicit finalize for engines that do not run through ``torch.autograd``."""

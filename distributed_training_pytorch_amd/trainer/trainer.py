@@ -126,7 +126,8 @@ class Trainer(object):
         self.step_timer = StepTimer(enabled=bool(step_timing))
         self.steps_this_epoch = None
         # capture the whole train step into one hipGraph (engine/graph.py); hooks opt in through
-        # self.graphed_step — only single-process runs without gradient accumulation are captured
+        # self.graphed_step — runs without gradient accumulation are captured; data-parallel ones only
+        # on the native RCCL transport (the reduction is then part of the graph)
         # keep whole (small enough) datasets resident on the GPU and gather batches there
         # (data/device_cache.py); falls back to the DataLoader when the dataset does not fit
         self.cache_dataset_on_device = bool(cache_dataset_on_device)
@@ -152,8 +153,9 @@ class Trainer(object):
             from ..engine.graph import GraphedTrainStep
             self.graphed_step = GraphedTrainStep(self.model, self.criterion, self.optimizer)
             if not self.graphed_step.enabled:
-                self.log("use_hip_graph: not capturable here (world size > 1, no parameter arena or an "
-                         "optimizer with per-step host arguments) - running eagerly", "warning")
+                self.log("use_hip_graph: not capturable here (world size > 1 without the native RCCL transport, "
+                         "sharded optimizer, no parameter arena or an optimizer with per-step host arguments) "
+                         "- running eagerly", "warning")
                 self.graphed_step = None
 
         # T7/T8 data

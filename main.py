@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("--ring-loader", action="store_true",
                     help="synthetic training data from native producer threads through the pinned host ring "
                          "(uint8 over PCIe on the copy stream); use with --synthetic --no-validate")
-    ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (1 process)")
+    ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (data-parallel: native RCCL transport only)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + per-bucket sharded optimizer + all-gather instead of all-reduce")
     ap.add_argument("--nproc", type=int, default=0,
