@@ -8,9 +8,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BF16 = torch.bfloat16
-N_IMG, HW, C, Co = int(os.environ.get("N", "256")), 56, int(os.environ.get("C", "256")), 256
+N_IMG, HW, C, Co = int(os.environ.get("N", "256")), int(os.environ.get("HW", "56")), int(os.environ.get("C", "256")), int(os.environ.get("CO", "256"))
+CFG = int(os.environ.get("CFG", "16"))
+BM = 512 if CFG == 17 else 256
 M = N_IMG * HW * HW
-tiles = (M + 255) // 256 * ((Co + 255) // 256)
+tiles = (M + BM - 1) // BM * ((Co + (128 if CFG == 17 else 256) - 1) // (128 if CFG == 17 else 256))
 stamps = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
 os.environ["DTP_IGEMM_STAMPS"] = hex(stamps.data_ptr())
 from distributed_training_pytorch_amd.ops import kernels as k  # noqa: E402
@@ -18,7 +20,7 @@ from distributed_training_pytorch_amd.ops import kernels as k  # noqa: E402
 x = torch.randn(N_IMG, HW, HW, C, device="cuda").to(BF16)
 w = (torch.randn(Co, 9 * C, device="cuda") * (2.0 / (9 * C)) ** 0.5).to(BF16)
 b = torch.zeros(Co, device="cuda")
-k._overrides["igemm"] = lambda M_, Nc, ks: (16, 1)
+k._overrides["igemm"] = lambda M_, Nc, ks: (CFG, 1)
 MODE = os.environ.get("MODE", "fprop")
 if MODE == "fprop":
     for _ in range(3):

@@ -67,6 +67,10 @@ _SIGS = {
 
 
 def lib_path(name="libdtp_hip.so"):
+    # DTP_HIP_LIB: another build of the kernel library, for same-box A/B runs of two source states
+    # (device-to-device clock spread on this pool is larger than most kernel changes)
+    if name == "libdtp_hip.so" and os.environ.get("DTP_HIP_LIB"):
+        return os.path.abspath(os.environ["DTP_HIP_LIB"])
     return os.path.join(_LIBDIR, name)
 
 
