@@ -208,6 +208,182 @@ __global__ __launch_bounds__(BN_T) void bn_apply_kernel(const u32x4_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Block ends (conv -> BN -> ReLU -> 2x2 max-pool): the normalised full-resolution activation z and
+// its gradient dz exist only inside these kernels.  Un-fused, a block-end layer costs 10.5
+// activation-sized passes over HBM per step (stats R; apply R+W; pool R + W/4; pool-bwd R/4 + W;
+// bwd-reduce 2R; bwd-apply 2R+W); fused it costs 5.75 (stats R; apply+pool R + W/4; bwd-reduce
+// R + R/4; bwd-apply R + R/4 + W) — every kernel here streams at the HBM rate, so passes are time.
+//
+// Work mapping (all three kernels): a workgroup owns pairs of pooled rows q = n*OH + oh; thread t
+// serves row 2*pair + (t >> 7) and the 16-byte vectors j = (t & 127) + 128*k of that row, so its
+// channel group g = j mod (C/8) is fixed (C/8 divides 128) and scale/shift stay in registers.
+// The 4-bit codes are maxpool2x2_fwd_kernel's: bits 1:0 the FIRST maximal window position (compared
+// on the bf16-rounded values, exactly what the un-fused pool sees), bit 2 "max > 0".
+struct PoolGeom { int NOH, OH, H, W, C, cg_shift; };
+
+DTP_DEVINL void bn_round_relu8(const u32x4_t v, const float* sc, const float* sh, float* z) {
+  float f[8];
+  unpack8(v, f);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {          // bf16 rounding, then ReLU: the values the un-fused z tensor holds
+    const uint32_t pk = pack_bf16x2(fmaxf(fmaf(f[2 * e], sc[2 * e], sh[2 * e]), 0.f),
+                                    fmaxf(fmaf(f[2 * e + 1], sc[2 * e + 1], sh[2 * e + 1]), 0.f));
+    z[2 * e] = __uint_as_float(pk << 16);
+    z[2 * e + 1] = __uint_as_float(pk & 0xFFFF0000u);
+  }
+}
+
+__global__ __launch_bounds__(BN_T) void bn_apply_pool_kernel(const u32x4_t* __restrict__ y, u32x4_t* __restrict__ zp,
+                                                             uint32_t* __restrict__ codes,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const PoolGeom gm) {
+  const int cg = gm.C >> 3, OW = gm.W >> 1, rowlen = OW * cg;
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127, g = t & (cg - 1);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc[e] = scale[g * 8 + e]; sh[e] = shift[g * 8 + e]; }
+  for (int q = 2 * blockIdx.x + half; q < gm.NOH; q += 2 * gridDim.x) {
+    const int n = q / gm.OH, oh = q - n * gm.OH;
+    const u32x4_t* r0 = y + ((size_t)n * gm.H + 2 * oh) * gm.W * cg;
+    const u32x4_t* r1 = r0 + (size_t)gm.W * cg;
+    for (int j = t; j < rowlen; j += 128) {
+      const int ow = j >> gm.cg_shift;
+      const int i0 = (2 * ow) * cg + g;
+      float za[8], zb[8], zc[8], zd[8];
+      bn_round_relu8(r0[i0], sc, sh, za);
+      bn_round_relu8(r0[i0 + cg], sc, sh, zb);
+      bn_round_relu8(r1[i0], sc, sh, zc);
+      bn_round_relu8(r1[i0 + cg], sc, sh, zd);
+      uint32_t code = 0;
+      float mx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        uint32_t arg = 0; float m = za[e];
+        if (zb[e] > m) { m = zb[e]; arg = 1; }
+        if (zc[e] > m) { m = zc[e]; arg = 2; }
+        if (zd[e] > m) { m = zd[e]; arg = 3; }
+        mx[e] = m;
+        code |= (arg | (m > 0.f ? 4u : 0u)) << (4 * e);
+      }
+      u32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)   // exact: the values are bf16 already
+        o[e] = (__float_as_uint(mx[2 * e]) >> 16) | (__float_as_uint(mx[2 * e + 1]) & 0xFFFF0000u);
+      const size_t oi = ((size_t)q * OW + ow) * cg + g;
+      zp[oi] = o;
+      codes[oi] = code;
+    }
+  }
+}
+
+// MODE 1 of bn_reduce_kernel for a pooled dz: only the window's winner carries a gradient, so
+// (sum dyh, sum dyh*xhat) needs y at the winner — all four vectors are read (one pass over y).
+__global__ __launch_bounds__(BN_T) void bn_reduce_pool_kernel(const u32x4_t* __restrict__ y,
+                                                              const u32x4_t* __restrict__ dzp,
+                                                              const uint32_t* __restrict__ codes,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              float* __restrict__ partial, const PoolGeom gm) {
+  __shared__ float red[2][2048];
+  const int cg = gm.C >> 3, OW = gm.W >> 1, rowlen = OW * cg;
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127, g = t & (cg - 1);
+  float a0[8], a1[8], mu[8], rs[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a0[e] = a1[e] = 0.f; mu[e] = mean[g * 8 + e]; rs[e] = rstd[g * 8 + e]; }
+  for (int q = 2 * blockIdx.x + half; q < gm.NOH; q += 2 * gridDim.x) {
+    const int n = q / gm.OH, oh = q - n * gm.OH;
+    const u32x4_t* r0 = y + ((size_t)n * gm.H + 2 * oh) * gm.W * cg;
+    const u32x4_t* r1 = r0 + (size_t)gm.W * cg;
+    for (int j = t; j < rowlen; j += 128) {
+      const int ow = j >> gm.cg_shift;
+      const int i0 = (2 * ow) * cg + g;
+      const size_t oi = ((size_t)q * OW + ow) * cg + g;
+      float fa[8], fb[8], fc[8], fd[8], d[8];
+      unpack8(r0[i0], fa); unpack8(r0[i0 + cg], fb); unpack8(r1[i0], fc); unpack8(r1[i0 + cg], fd);
+      unpack8(dzp[oi], d);
+      const uint32_t code = codes[oi];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t c4 = (code >> (4 * e)) & 15u, arg = c4 & 3u;
+        const float dyh = (c4 & 4u) ? d[e] : 0.f;
+        const float yw = arg == 0 ? fa[e] : (arg == 1 ? fb[e] : (arg == 2 ? fc[e] : fd[e]));
+        a0[e] += dyh;
+        a1[e] = fmaf(dyh, (yw - mu[e]) * rs[e], a1[e]);
+      }
+    }
+  }
+  // fold the BN_T / cg threads that share a channel group (thread -> slot threadIdx.x / cg)
+  const int slot = (threadIdx.x >> gm.cg_shift), R = BN_T >> gm.cg_shift;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][slot * gm.C + g * 8 + e] = a0[e];
+    red[1][slot * gm.C + g * 8 + e] = a1[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * gm.C; c += BN_T) {
+    const int which = c / gm.C, ch = c - which * gm.C;
+    float s = 0.f;
+    for (int k = 0; k < R; ++k) s += red[which][k * gm.C + ch];
+    partial[((size_t)blockIdx.x * 2 + which) * gm.C + ch] = s;
+  }
+}
+
+// MODE 1 of bn_apply_kernel for a pooled dz: dy = g*(dyh - c1 - xhat*c2) at all four window
+// positions, dyh = dz_pooled at the winner (when its z > 0), 0 elsewhere.
+__global__ __launch_bounds__(BN_T) void bn_bwd_apply_pool_kernel(const u32x4_t* __restrict__ y,
+                                                                 const u32x4_t* __restrict__ dzp,
+                                                                 const uint32_t* __restrict__ codes,
+                                                                 u32x4_t* __restrict__ dy,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd,
+                                                                 const float* __restrict__ c1,
+                                                                 const float* __restrict__ c2,
+                                                                 const float* __restrict__ gamma, const PoolGeom gm) {
+  const int cg = gm.C >> 3, OW = gm.W >> 1, rowlen = OW * cg;
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127, g = t & (cg - 1);
+  float gs[8], ka[8], kb[8];       // dy = gs*dyh + (ka + y*kb):  ka = -gs*(c1 - mu*rs*c2), kb = -gs*rs*c2
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float mu = mean[g * 8 + e], rs = rstd[g * 8 + e], k1 = c1[g * 8 + e], k2 = c2[g * 8 + e];
+    gs[e] = gamma[g * 8 + e] * rs;
+    ka[e] = -gs[e] * (k1 - mu * rs * k2);
+    kb[e] = -gs[e] * rs * k2;
+  }
+  for (int q = 2 * blockIdx.x + half; q < gm.NOH; q += 2 * gridDim.x) {
+    const int n = q / gm.OH, oh = q - n * gm.OH;
+    const size_t row0 = ((size_t)n * gm.H + 2 * oh) * gm.W * cg, row1 = row0 + (size_t)gm.W * cg;
+    for (int j = t; j < rowlen; j += 128) {
+      const int ow = j >> gm.cg_shift;
+      const int i0 = (2 * ow) * cg + g;
+      const size_t oi = ((size_t)q * OW + ow) * cg + g;
+      float f[4][8], d[8];
+      unpack8(y[row0 + i0], f[0]); unpack8(y[row0 + i0 + cg], f[1]);
+      unpack8(y[row1 + i0], f[2]); unpack8(y[row1 + i0 + cg], f[3]);
+      unpack8(dzp[oi], d);
+      const uint32_t code = codes[oi];
+      float gd[8];
+      uint32_t arg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t c4 = (code >> (4 * e)) & 15u;
+        arg[e] = c4 & 3u;
+        gd[e] = (c4 & 4u) ? gs[e] * d[e] : 0.f;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(f[p][e], kb[e], ka[e]) + (arg[e] == (uint32_t)p ? gd[e] : 0.f);
+        u32x4_t v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pack_bf16x2(o[2 * e], o[2 * e + 1]);
+        dy[((p & 2) ? row1 : row0) + i0 + ((p & 1) ? cg : 0)] = v;
+      }
+    }
+  }
+}
+
 int bn_grid(long M, int C) {
   const int R = BN_T / (C >> 3);
   long blocks = (M + (long)R * 8 - 1) / ((long)R * 8);      // >= 8 rows per thread
@@ -274,5 +450,53 @@ extern "C" int dtp_bn_bwd(const void* y, const void* dz, void* dy, const float* 
   if (g < 1) g = 1;
   hipLaunchKernelGGL(bn_apply_kernel<1>, dim3((int)g), dim3(BN_T), 0, s, (const u32x4_t*)y, (const u32x4_t*)dz,
                      (u32x4_t*)dy, scale, shift, mean, rstd, work, work + C, gamma, nvec, C, relu);
+  return DTP_CHECK_LAUNCH();
+}
+
+// ---- block-end forms: BN + ReLU + 2x2/s2 max-pool (training).  y: [N][H][W][C] bf16, H and W even.
+static bool bn_pool_geom(PoolGeom& gm, int N, int H, int W, int C) {
+  if (N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1) || !bn_shape_ok((long)N * H * W, C)) return false;
+  if ((long)N * (H / 2) > 0x7fffffffL) return false;
+  gm.NOH = N * (H / 2); gm.OH = H / 2; gm.H = H; gm.W = W; gm.C = C; gm.cg_shift = __builtin_ctz(C >> 3);
+  return true;
+}
+static int bn_pool_grid(const PoolGeom& gm) {
+  long b = ((long)gm.NOH + 1) / 2;
+  if (b > BN_MAXBLK) b = BN_MAXBLK;
+  return (int)(b < 1 ? 1 : b);
+}
+
+// zp: [N][H/2][W/2][C] bf16, codes: [N][H/2][W/2][C/8] uint32; stats / partial as dtp_bn_fwd_train
+extern "C" int dtp_bn_fwd_train_pool(const void* y, void* zp, void* codes, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float* stats, float* partial, int N,
+                                     int H, int W, int C, float eps, float momentum, hipStream_t s) {
+  PoolGeom gm;
+  if (!bn_pool_geom(gm, N, H, W, C)) return -10;
+  const long M = (long)N * H * W;
+  const int nblk = bn_grid(M, C);
+  float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, partial, M, C, 1);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, eps,
+                     momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(2 * bn_pool_grid(gm)), dim3(BN_T), 0, s, (const u32x4_t*)y,
+                     (u32x4_t*)zp, (uint32_t*)codes, scale, shift, gm);
+  return DTP_CHECK_LAUNCH();
+}
+
+extern "C" int dtp_bn_bwd_pool(const void* y, const void* dzp, const void* codes, void* dy, const float* gamma,
+                               const float* stats, void* dgamma, void* dbeta, int grads_fp32, float beta_g,
+                               float beta_b, float* partial, float* work, int N, int H, int W, int C, hipStream_t s) {
+  PoolGeom gm;
+  if (!bn_pool_geom(gm, N, H, W, C)) return -10;
+  const long M = (long)N * H * W;
+  const float *mean = stats, *rstd = stats + C;
+  const int nblk = bn_pool_grid(gm);
+  hipLaunchKernelGGL(bn_reduce_pool_kernel, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, (const u32x4_t*)dzp,
+                     (const uint32_t*)codes, mean, rstd, partial, gm);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M,
+                     dgamma, dbeta, grads_fp32, beta_g, beta_b, work, work + C);
+  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(2 * nblk), dim3(BN_T), 0, s, (const u32x4_t*)y,
+                     (const u32x4_t*)dzp, (const uint32_t*)codes, (u32x4_t*)dy, mean, rstd, work, work + C, gamma, gm);
   return DTP_CHECK_LAUNCH();
 }

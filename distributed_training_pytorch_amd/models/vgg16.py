@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ..ops.layers import (AvgPoolFlatten, BatchNormReLU, Conv3x3, ConvFirst, Linear, MaxPool2x2, ReLUMarker,
-                          conv_bn_relu_folded, conv_relu_pool)
+                          bn_relu_pool, conv_bn_relu_folded, conv_relu_pool)
 from .fused_model import FusedModel
 
 
@@ -87,6 +87,19 @@ class ConvBlock(nn.Module):
                 x = m(x)
                 i += 1
             return x
+        if x.is_cuda and self.batch_norm and self.training:
+            # training: the block's last BatchNorm + ReLU + max-pool is one kernel pair — the
+            # normalised full-resolution activation and its gradient never reach HBM
+            mods = list(self.conv)
+            if isinstance(mods[-1], MaxPool2x2) and isinstance(mods[-3], BatchNormReLU):
+                for m in mods[:-3]:
+                    x = m(x)
+                y = bn_relu_pool(mods[-3], x)
+                if y is not None:
+                    return y
+                for m in mods[-3:]:
+                    x = m(x)
+                return x
         return self.conv(x)
 
 

@@ -714,6 +714,56 @@ def bn_bwd(y, dz, gamma, stats, dgamma, dbeta, beta_g=0.0, beta_b=0.0, relu=True
     return dy
 
 
+def bn_pool_fusable(y):
+    """BatchNorm + ReLU + 2x2 max-pool as one kernel pair: NHWC bf16, even H and W, C a power of two in 64..512."""
+    if y.dim() != 4 or not y.is_cuda or y.dtype != BF16:
+        return False
+    N, H, W, C = y.shape
+    return H >= 2 and W >= 2 and H % 2 == 0 and W % 2 == 0 and 64 <= C <= 512 and (C & (C - 1)) == 0
+
+
+def bn_fwd_train_pool(y, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """maxpool2x2(relu(batch_norm(y))) with the batch statistics for NHWC bf16 y [N, H, W, C]: the
+    normalised full-resolution activation is never written.  Returns (z_pooled, codes, stats);
+    codes are :func:`maxpool2x2_fwd`'s 4-bit (first argmax, max > 0) codes."""
+    if not bn_pool_fusable(y):
+        raise ValueError("bn_fwd_train_pool: shape %s" % (tuple(y.shape),))
+    N, H, W, C = y.shape
+    _bn_check(y, C, gamma, beta, running_mean, running_var)
+    zp = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=y.device)
+    codes = torch.empty((N, H // 2, W // 2, C // 8), dtype=torch.int32, device=y.device)
+    stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
+    part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    check(_lib.hip().dtp_bn_fwd_train_pool(ptr(y), ptr(zp), ptr(codes), ptr(gamma), ptr(beta), ptr(running_mean),
+                                           ptr(running_var), ptr(stats), ptr(part), N, H, W, C, float(eps),
+                                           float(momentum), stream()), "bn_fwd_train_pool")
+    return zp, codes, stats
+
+
+def bn_bwd_pool(y, dzp, codes, gamma, stats, dgamma, dbeta, beta_g=0.0, beta_b=0.0):
+    """dy of :func:`bn_fwd_train_pool` from the POOLED incoming gradient: the full-resolution
+    gradient of the normalised activation is never materialised."""
+    if not bn_pool_fusable(y):
+        raise ValueError("bn_bwd_pool: shape %s" % (tuple(y.shape),))
+    N, H, W, C = y.shape
+    _bn_check(y, C, gamma)
+    _need(dzp, BF16, "dzp")
+    if tuple(dzp.shape) != (N, H // 2, W // 2, C) or tuple(codes.shape) != (N, H // 2, W // 2, C // 8) \
+            or codes.dtype != torch.int32 or not codes.is_contiguous() or stats.numel() != 4 * C \
+            or stats.dtype != torch.float32:
+        raise ValueError("bn_bwd_pool: bad shapes")
+    if dgamma.dtype != dbeta.dtype or dgamma.dtype not in (torch.float32, BF16) or dgamma.numel() != C \
+            or dbeta.numel() != C or not dgamma.is_contiguous() or not dbeta.is_contiguous():
+        raise ValueError("bn_bwd_pool: dgamma / dbeta must be contiguous [C] of one dtype (f32 / bf16)")
+    dy = torch.empty_like(y)
+    part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    work = workspace.get("bn_work", 2 * 512, torch.float32, y.device)
+    check(_lib.hip().dtp_bn_bwd_pool(ptr(y), ptr(dzp), ptr(codes), ptr(dy), ptr(gamma), ptr(stats), ptr(dgamma),
+                                     ptr(dbeta), int(dgamma.dtype == torch.float32), float(beta_g), float(beta_b),
+                                     ptr(part), ptr(work), N, H, W, C, stream()), "bn_bwd_pool")
+    return dy
+
+
 def cast_f32_bf16(src, dst):
     _need(src, torch.float32, "src")
     _need(dst, BF16, "dst")

@@ -599,6 +599,48 @@ class _BatchNormReLUFn(torch.autograd.Function):
         return dy, None, None, None
 
 
+class _BatchNormReLUPoolFn(torch.autograd.Function):
+    """Block end of VGG16-BN: BatchNorm + ReLU + 2x2 max-pool.  Forward writes only the pooled
+    activation and the pool codes; backward goes from the pooled gradient straight to the
+    convolution's incoming gradient (csrc/bn.hip, "block ends": 5.75 instead of 10.5
+    activation-sized HBM passes for the layer)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, layer):
+        arena = _arena_of(layer)
+        y = y.contiguous()
+        zp, codes, stats = K.bn_fwd_train_pool(y, arena.flat_slice(arena.flat_master, weight),
+                                               arena.flat_slice(arena.flat_master, bias), layer.running_mean,
+                                               layer.running_var, layer.eps, layer.momentum)
+        ctx.layer = layer
+        ctx.save_for_backward(y, codes, stats, weight, bias)
+        ctx.mark_non_differentiable(codes)
+        return zp
+
+    @staticmethod
+    def backward(ctx, dzp):
+        layer = ctx.layer
+        arena = _arena_of(layer)
+        y, codes, stats, weight, bias = ctx.saved_tensors
+        dy = K.bn_bwd_pool(y, dzp.contiguous(), codes, arena.flat_slice(arena.flat_master, weight), stats,
+                           arena.grad(weight), arena.grad(bias), arena.grad_beta(weight), arena.grad_beta(bias))
+        arena.notify_grad_ready(bias)
+        arena.notify_grad_ready(weight)
+        return dy, None, None, None
+
+
+FUSE_BN_POOL = os.environ.get("DTP_FUSE_BN_POOL", "1") != "0"      # A/B switch
+
+
+def bn_relu_pool(bn, y):
+    """``maxpool2x2(relu(bn(y)))`` in training mode as the fused kernel pair, or None when the shape
+    (or the mode) does not allow it and the caller runs the three modules one after the other."""
+    if not (FUSE_BN_POOL and bn.training and bn.relu and y.is_cuda and K.bn_pool_fusable(y)):
+        return None
+    bn.num_batches_tracked += 1
+    return _BatchNormReLUPoolFn.apply(y, bn.weight, bn.bias, bn)
+
+
 class BatchNormReLU(FusedLayer):
     """BatchNorm2d over the channel axis of the internal NHWC bf16 layout with the following ReLU
     fused (VGG16-BN, BASELINE.json config 5).  Parameter and buffer names are ``nn.BatchNorm2d``'s

@@ -797,6 +797,47 @@ def test_batchnorm_relu_fwd_bwd_against_torch(shape, relu):
     assert torch.equal(z, z2) and torch.equal(stats, stats2)
 
 
+@pytest.mark.parametrize("shape", [(4, 14, 14, 64), (3, 8, 6, 128), (2, 28, 28, 256), (5, 14, 14, 512), (16, 112, 112, 64)])
+def test_batchnorm_relu_pool_fused_matches_the_three_kernels(shape):
+    """Block-end fusion (bn_fwd_train_pool / bn_bwd_pool) against the un-fused chain of this
+    library's own kernels, which the test above pins to F.batch_norm: pooled activation, pool codes,
+    statistics and running statistics bit for bit; dY / d(gamma) / d(beta) to rounding (the fused
+    backward evaluates the same expression in a different association)."""
+    k = _k()
+    N, H, W, C = shape
+    torch.manual_seed(33)
+    y = (_rand(N, H, W, C).float() * (1.0 + torch.arange(C, device="cuda") % 5) + 0.3 * (torch.arange(C, device="cuda") % 7 - 3)).to(BF16)
+    y[0, :2, :2, :8] = 0.25                      # an exact four-way tie: the FIRST window element must win
+    dzp = _rand(N, H // 2, W // 2, C, scale=0.1)
+    gamma = (1.0 + 0.2 * torch.randn(C, device="cuda")).contiguous()
+    beta = (0.3 * torch.randn(C, device="cuda")).contiguous()
+    rm, rv = 0.1 * torch.randn(C, device="cuda"), 0.5 + torch.rand(C, device="cuda")
+    rm_a, rv_a, rm_b, rv_b = rm.clone(), rv.clone(), rm.clone(), rv.clone()
+    z, stats = k.bn_fwd_train(y, gamma, beta, rm_a, rv_a, relu=True)
+    zp_ref, codes_ref = k.maxpool2x2_fwd(z, want_idx=True)
+    zp, codes, stats_f = k.bn_fwd_train_pool(y, gamma, beta, rm_b, rv_b)
+    assert torch.equal(stats, stats_f) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    assert torch.equal(zp, zp_ref), "pooled activation %s" % (shape,)
+    assert torch.equal(codes, codes_ref), "pool codes %s" % (shape,)
+    for dt in (torch.float32, BF16):
+        dg_r, db_r = torch.full((C,), 0.25, device="cuda", dtype=dt), torch.full((C,), -0.5, device="cuda", dtype=dt)
+        dg_f, db_f = dg_r.clone(), db_r.clone()
+        k.fuse_colsum = False
+        try:
+            dz = k.maxpool2x2_bwd(None, dzp, relu_mask=True, idx=codes_ref, in_shape=(N, H, W, C))
+        finally:
+            k.fuse_colsum = True
+        dy_ref = k.bn_bwd(y, dz, gamma, stats, dg_r, db_r, beta_g=1.0, beta_b=1.0, relu=True)
+        dy = k.bn_bwd_pool(y, dzp, codes, gamma, stats, dg_f, db_f, beta_g=1.0, beta_b=1.0)
+        tol = 2e-2 if dt == BF16 else 2e-3
+        assert (dg_f.float() - dg_r.float()).abs().max().item() <= tol * (dg_r.float().abs().max().item() + 1.0)
+        assert (db_f.float() - db_r.float()).abs().max().item() <= tol * (db_r.float().abs().max().item() + 1.0)
+        _close(dy, dy_ref.float(), 2e-2, 2e-2 * dy_ref.float().abs().max().item() + 1e-6, "fused bn+pool dy %s" % (shape,))
+    # determinism
+    zp2, codes2, _ = k.bn_fwd_train_pool(y, gamma, beta, rm.clone(), rv.clone())
+    assert torch.equal(zp, zp2) and torch.equal(codes, codes2)
+
+
 VGG_LAYERS = [  # every 3x3 layer of VGG16 after conv1_1: (Cin, Cout, H = W)
     (64, 64, 224), (64, 128, 112), (128, 128, 112), (128, 256, 56), (256, 256, 56), (256, 256, 56),
     (256, 512, 28), (512, 512, 28), (512, 512, 28), (512, 512, 14), (512, 512, 14), (512, 512, 14),
