@@ -32,7 +32,10 @@ def scenario_gpu_shared(out):
                                                              MaxPool2x2, SoftmaxCrossEntropy)
     from distributed_training_pytorch_amd.ops.optim import FusedSGD
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", 0)
+    # one-GPU box: every rank on cuda:0 over gloo; DTP_TEST_MULTI_GPU=1 (tests/test_multi_gpu.py, boxes with
+    # >= world GPUs): one GPU per rank, RCCL process group, native RCCL gradient transport
+    multi = os.environ.get("DTP_TEST_MULTI_GPU") == "1"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if multi else 0)
     torch.cuda.set_device(dev)
 
     class TinyNet(FusedModel):
@@ -54,6 +57,8 @@ def scenario_gpu_shared(out):
     net = TinyNet().to(dev)
     dp = DataParallel(net, bucket_cap_mb=0.05, first_bucket_mb=0.01)
     assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
+    if multi:
+        assert type(dp.reducer.transport).__name__ == "NativeRcclTransport", dp.reducer.transport.info
     torch.cuda.synchronize()
     assert _allclose_across_ranks(net.param_arena.flat_master.cpu()), "broadcast of initial parameters failed"
     opt = FusedSGD(net, lr=0.05, momentum=0.9)
@@ -78,7 +83,10 @@ def scenario_gpu_shared(out):
     torch.cuda.synchronize()
     assert all(l == l for l in losses), losses
     assert _allclose_across_ranks(a.flat_master.cpu()), "parameters diverged across ranks"
-    assert dp.reducer.stats["launched"] == 6 * len(dp.reducer.buckets)
+    if not multi:
+        assert dp.reducer.stats["launched"] == 6 * len(dp.reducer.buckets)
+    # large-batch reference on this rank (fresh model, rank 0's initial weights are gone: compare the
+    # FINAL parameters across ranks above, and the loss trajectory against a single-process run below)
     dp.close()
     open(os.path.join(out, "losses.%d" % rank), "w").write(json.dumps(dict(losses=losses)))
 
@@ -274,7 +282,8 @@ def scenario_fault(out):
 
 if __name__ == "__main__":
     scenario, out = sys.argv[1], sys.argv[2]
-    penv.ddp_setup("gloo", timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
+    penv.ddp_setup("nccl" if os.environ.get("DTP_TEST_MULTI_GPU") == "1" else "gloo",
+                   timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
     {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault,
      "gpu_shared": scenario_gpu_shared, "sharded": scenario_sharded, "small_val": scenario_small_val}[scenario](out)
     comm.barrier()
