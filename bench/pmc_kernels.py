@@ -38,5 +38,16 @@ x = torch.randn(N, 3, 224, 224, device="cuda")
 w1 = (torch.randn(64, 27, device="cuda") * 0.27).to(BF16)
 y = k.conv1_fprop(x, w1, torch.zeros(64, device="cuda"))
 k.maxpool2x2_bwd(y, k.maxpool2x2_fwd(y), relu_mask=True)
+# the kernels the training step really uses at the first layer / the pools (round 2)
+dy1 = (torch.randn(N, 224, 224, 64, device="cuda") * 0.1).to(BF16)
+gw1, gb1 = torch.empty(64, 27, device="cuda"), torch.empty(64, device="cuda")
+k.conv1_wgrad(x, dy1, gw1, gb1, mask_w=w1, mask_bias=torch.zeros(64, device="cuda"))
+yp, idx = k.maxpool2x2_fwd(y, want_idx=True)
+k.maxpool2x2_bwd(None, torch.randn_like(yp), relu_mask=True, idx=idx, in_shape=tuple(y.shape))
+# VGG16-BN block end (config 5): BatchNorm + ReLU + pool as one kernel pair
+g, b = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+zp, codes, stats = k.bn_fwd_train_pool(y, g, b, rm, rv)
+k.bn_bwd_pool(y, torch.randn_like(zp), codes, g, stats, torch.empty(64, device="cuda"), torch.empty(64, device="cuda"))
 torch.cuda.synchronize()
 print("pmc driver done")
