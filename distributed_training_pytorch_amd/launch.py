@@ -41,7 +41,9 @@ def rccl_env_defaults(nnodes=1):
         # surface a dead peer as an error in the process group instead of a silent hang
         "TORCH_NCCL_ASYNC_ERROR_HANDLING": "1",
         "TORCH_FR_BUFFER_SIZE": "2000",              # flight recorder (reference run.sh:8 sets its older name)
-        "NCCL_DEBUG": "WARN",
+        # NCCL_DEBUG stays unset here on purpose: RCCL writes its WARN lines (e.g. the iommu=pt notice
+        # many hosts trigger) to STDOUT, and bench.py promises one machine-readable line there;
+        # run.sh, the operator-facing launcher, exports NCCL_DEBUG=WARN
     }
     if nnodes > 1:
         env["NCCL_SOCKET_IFNAME"] = "eno1"            # reference run.sh:3 (bootstrap interface)

@@ -95,6 +95,11 @@ def test_launcher_falls_back_to_torch_transport_and_restarts(tmp_path):
         rank, mode = os.environ["RANK"], os.environ.get("DTP_TRANSPORT", "auto")
         open(os.path.join(sys.argv[1], "run.%s.%s" % (mode, rank)), "w").close()
         if mode != "torch":
+            if rank == "1":          # give up only once rank 0 is seen running (the launcher stops it then)
+                import time
+                t0 = time.time()
+                while not os.path.exists(os.path.join(sys.argv[1], "run.%s.0" % mode)) and time.time() - t0 < 60:
+                    time.sleep(0.05)
             sys.exit(EXIT_NATIVE_BRINGUP if rank == "1" else 0)
         assert os.environ["DTP_NATIVE_FELL_BACK"] == "1"
     """)
