@@ -81,6 +81,12 @@ def main(argv=None):
         sys.exit(self_launch(args, argv))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+    # stdout carries ONE line, the JSON result of rank 0.  Libraries below us write there too (RCCL's
+    # version banner and WARN lines, gloo's "Rank 0 is connected to ..." notices), so file descriptor 1
+    # points at stderr for the duration of the run and is restored for the result line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("DTP_BENCH_DUMP_AFTER"):      # debugging aid: dump every thread's stack and exit
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["DTP_BENCH_DUMP_AFTER"]), exit=True)
@@ -204,6 +210,8 @@ def main(argv=None):
         value = global_batch * args.steps / dt
         info = getattr(tr, "info", None) or {}
         plain = not (args.batch_norm or args.fp8_classifier)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps({
             "metric": "train images/sec (whole node) VGG16 bf16 224px",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -235,6 +243,8 @@ def main(argv=None):
                        "grad_dtype": args.grad_dtype if on_gpu else "fp32", "grad_accum": args.grad_accum,
                        "fp8_classifier": bool(args.fp8_classifier), "backend": backend,
                        "grad_transport": type(tr).__name__}}), flush=True)
+        os.dup2(2, 1)                       # teardown chatter (communicator destruction) stays off stdout
+    os.close(real_stdout)
     if on_gpu:
         torch.cuda.synchronize()
     if hasattr(data, "close"):
