@@ -182,6 +182,7 @@ def main(argv=None):
     fence()
     exposed0 = dp.reducer.exposed_ms_total()
     wait0 = getattr(data, "wait_ms_total", lambda: 0.0)()
+    starved0 = getattr(data, "starved_ms_total", lambda: 0.0)()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -189,6 +190,7 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     exposed = (dp.reducer.exposed_ms_total() - exposed0) / max(1, args.steps)
     data_wait = (getattr(data, "wait_ms_total", lambda: 0.0)() - wait0) / max(1, args.steps)
+    data_starved = (getattr(data, "starved_ms_total", lambda: 0.0)() - starved0) / max(1, args.steps)
     cdev = dev if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([dt], device=cdev, dtype=torch.float64)
     ones = torch.ones(1, device=cdev, dtype=torch.float64)
@@ -226,6 +228,7 @@ def main(argv=None):
             "max_memory_reserved_gb": (torch.cuda.max_memory_reserved(dev) / 2 ** 30) if on_gpu else 0.0,
             "allreduce_exposed_ms_per_step": exposed,     # compute stream idle waiting for gradient buckets (rank 0)
             "data_wait_ms_per_step": data_wait,           # host blocked on the input ring (rank 0)
+            "data_starved_ms_per_step": data_starved,     # compute stream idle waiting for its batch's H2D copy
             "ranks_seen": ranks_seen,
             "grad_transport": type(tr).__name__,
             "grad_transport_selfcheck_ok": transport_ok,

@@ -25,6 +25,39 @@ def _align(n, a=256):
     return (n + a - 1) // a * a
 
 
+class StreamStallMeter(object):
+    """How long a stream sat in a ``wait_event`` — the GPU-side definition of "starved for input".
+    An event recorded right before the wait completes when the stream's EARLIER work is done, one
+    recorded right after it completes when the awaited copy has landed as well: the difference is
+    time the compute stream had nothing to run because its batch was not there.  (Host-side time in
+    ``next(loader)`` cannot tell this from back-pressure: a host that runs ahead of the GPU blocks in
+    the loader for most of every step without the GPU ever waiting.)  Events are read lazily, only
+    those that completed; never a host synchronisation."""
+
+    def __init__(self):
+        self._pairs, self._ms = [], 0.0
+
+    def before(self, stream):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        return e0
+
+    def after(self, e0, stream):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(stream)
+        self._pairs.append((e0, e1))
+
+    def total_ms(self):
+        keep = []
+        for e0, e1 in self._pairs:
+            if e1.query():
+                self._ms += e0.elapsed_time(e1)
+            else:
+                keep.append((e0, e1))
+        self._pairs = keep
+        return self._ms
+
+
 class DevicePrefetcher(object):
     def __init__(self, loader, device, depth=2, ring_slots=4):
         self.loader = loader
@@ -36,6 +69,7 @@ class DevicePrefetcher(object):
         self._k = 0
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.host_wait_s = 0.0          # time the host spent waiting for a ring slot to drain
+        self.stall = StreamStallMeter() if self.cuda else None
 
     def __len__(self):
         return len(self.loader)
@@ -114,11 +148,22 @@ class DevicePrefetcher(object):
             except StopIteration:
                 pass
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cs = torch.cuda.current_stream(self.device)
+                e0 = self.stall.before(cs)
+                cs.wait_event(ev)
+                self.stall.after(e0, cs)
                 for e in batch:
                     if torch.is_tensor(e):
                         e.record_stream(torch.cuda.current_stream(self.device))
             yield batch
+
+
+    def starved_ms_total(self):
+        """GPU-side input stall so far (ms): the compute stream waiting for a batch's copy."""
+        src = getattr(self.loader, "src", None)
+        if getattr(self.loader, "yields_device_batches", False) and hasattr(src, "starved_ms_total"):
+            return src.starved_ms_total()
+        return self.stall.total_ms() if self.stall is not None else 0.0
 
 
 class PinnedRingSource(object):
@@ -153,6 +198,7 @@ class PinnedRingSource(object):
         # the generator's pixels are ~N(128, 37) + a class band: (x/64 - 2) keeps activations O(1)
         self.normalization = (1.0 / 64.0, (2.0,) * channels, (1.0,) * channels)
         self._wait_s = 0.0
+        self.stall = StreamStallMeter()
         self._k = 0
         self._thread = None
         if self.refill:
@@ -199,7 +245,10 @@ class PinnedRingSource(object):
     def __next__(self):
         k = self._k
         self._k += 1
+        cs = torch.cuda.current_stream(self.device)
+        e0 = self.stall.before(cs)
         self.ring.consumer_wait(k % self.n)              # device-side: compute waits for copy k
+        self.stall.after(e0, cs)
         # (without refill the slots are read-only after start-up: nothing on the host ever waits —
         # the host may run several steps ahead of the device, like with device-resident data)
         self._queue(k + 1)
@@ -209,6 +258,10 @@ class PinnedRingSource(object):
 
     def wait_ms_total(self):
         return 1e3 * self._wait_s
+
+    def starved_ms_total(self):
+        """GPU-side input stall so far (ms): the compute stream waiting for its batch's H2D copy."""
+        return self.stall.total_ms()
 
     def close(self):
         if self._thread is not None:

@@ -321,7 +321,9 @@ class Trainer(object):
                     self.steps_this_epoch = min(self.steps_this_epoch, self.max_steps_per_epoch)
             except TypeError:       # a loader without a length: windows cannot be flushed at the end
                 self.steps_this_epoch = None
-            loop = self._progress(DevicePrefetcher(self.train_dataloader, self.device))
+            prefetcher = DevicePrefetcher(self.train_dataloader, self.device)
+            starved0 = prefetcher.starved_ms_total()
+            loop = self._progress(prefetcher)
             it, i = iter(loop), -1
             data_wait_s = step_host_s = 0.0
             reducer = getattr(self.model, "reducer", None)
@@ -391,7 +393,11 @@ class Trainer(object):
                 self._write_metrics(dict(
                     epoch=epoch + 1, images_per_sec=ips, steps=steps_done,
                     **{"gpu_%s_ms_per_step" % k: v["total_ms"] / steps_done for k, v in phases.items()},
-                    data_wait_ms_per_step=1e3 * data_wait_s / steps_done,      # host blocked on the loader
+                    # host blocked in next(loader): starvation OR back-pressure (a host that runs ahead
+                    # of the GPU waits here for a free slot of the copy pipeline most of every step)
+                    data_wait_ms_per_step=1e3 * data_wait_s / steps_done,
+                    # GPU-side: the compute stream idle because its batch's copy had not landed
+                    data_starved_ms_per_step=(prefetcher.starved_ms_total() - starved0) / steps_done,
                     host_step_ms_per_step=1e3 * step_host_s / steps_done,      # host time inside train_step
                     allreduce_exposed_ms_per_step=exposed / steps_done,        # GPU idle waiting for buckets
                     **{"train_" + k: v for k, v in glob.items()}))
