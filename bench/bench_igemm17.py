@@ -30,8 +30,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", default="gpurun_out/igemm17.jsonl")
+    ap.add_argument("--cfgs", default="3,17", help="two igemm cfg ids to alternate (18: 3-stage ring, two workgroups per CU)")
     args = ap.parse_args()
     N = args.batch
+    ca, cb = [int(c) for c in args.cfgs.split(",")]
     out = open(args.out, "w")
     for name, C, Co, HW, kind in [("conv2_2 fprop", 128, 128, 112, "f"), ("conv2_2 dgrad", 128, 128, 112, "d"),
                                   ("conv3_1 dgrad", 128, 256, 56, "d")]:
@@ -44,7 +46,7 @@ def main():
         fn = (lambda: k.conv3x3_fprop(x, w, b, True)) if kind == "f" else (lambda: k.conv3x3_dgrad(dy, wd, mask_src=x))
         rec = dict(layer=name, batch=N, gflop=flops / 1e9)
         outs = {}
-        for cfg in (3, 17, 3, 17):
+        for cfg in (ca, cb, ca, cb, ca, cb):
             k._overrides["igemm"] = lambda M, Nc, ks, cfg=cfg: (cfg, 1)
             try:
                 ms = timeit(fn)
@@ -53,7 +55,9 @@ def main():
                 k._overrides.pop("igemm")
             rec.setdefault("cfg%d_ms" % cfg, []).append(round(ms, 4))
             rec["cfg%d_tf" % cfg] = round(flops / ms / 1e9, 1)
-        rec["bit_equal"] = bool(torch.equal(outs[3], outs[17]))
+        rec["bit_equal"] = bool(torch.equal(outs[ca], outs[cb]))
+        rec["max_abs_diff"] = float((outs[ca].float() - outs[cb].float()).abs().max())
+        rec["ref_abs_max"] = float(outs[ca].float().abs().max())
         print(json.dumps(rec), flush=True)
         out.write(json.dumps(rec) + "\n")
         del x, dy, w, wd, outs

@@ -12,7 +12,8 @@ N_IMG, HW, C, Co = int(os.environ.get("N", "256")), int(os.environ.get("HW", "56
 CFG = int(os.environ.get("CFG", "16"))
 BM = 512 if CFG == 17 else 256
 M = N_IMG * HW * HW
-tiles = (M + BM - 1) // BM * ((Co + (128 if CFG == 17 else 256) - 1) // (128 if CFG == 17 else 256))
+BN = 128 if CFG in (17, 18) else 256
+tiles = (M + BM - 1) // BM * ((Co + BN - 1) // BN)
 stamps = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
 os.environ["DTP_IGEMM_STAMPS"] = hex(stamps.data_ptr())
 from distributed_training_pytorch_amd.ops import kernels as k  # noqa: E402
