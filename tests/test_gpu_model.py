@@ -613,6 +613,9 @@ def test_pinned_ring_input_pipeline():
     assert not torch.equal(seen[0], seen[1]) and torch.equal(seen[0], seen[3])     # 3 distinct slots, cycled
     assert 100 < float(seen[0].float().mean()) < 160                                # ~N(128, .) pixels
     assert src.wait_ms_total() == 0.0 and src.ring.stats()["copies"] == 2 * 8
+    torch.cuda.synchronize()
+    stall = src.starved_ms_total()          # GPU-side input stall: HIP events around the stream's wait for the copy
+    assert 0.0 <= stall < 1e3 and not src.stall._pairs, stall       # every pair was read after the sync
     src.close()
 
     # (b) generic loader path
@@ -620,6 +623,8 @@ def test_pinned_ring_input_pipeline():
     pf = DevicePrefetcher(data, dev)
     got = list(pf)
     assert pf.ring is not None and pf.ring.stats()["copies"] == 10                  # every tensor went through a slot
+    torch.cuda.synchronize()
+    assert 0.0 <= pf.starved_ms_total() < 1e3
     for (a, b), (ga, gb) in zip(data, got):
         assert ga.is_cuda and torch.equal(ga.cpu(), a) and torch.equal(gb.cpu(), b)
     pinned = [(a.pin_memory(), b.pin_memory()) for a, b in data]
