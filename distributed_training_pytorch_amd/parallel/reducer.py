@@ -38,12 +38,18 @@ from ..utils.profiler import trace_range
 from . import comm
 
 
-def plan_buckets(numels, elem_bytes, first_cap_bytes, cap_bytes, split_large_bytes=None):
+def plan_buckets(numels, elem_bytes, first_cap_bytes, cap_bytes, split_large_bytes=None, tail_cap_bytes=None):
     """Group parameter indices (given in *registration* order) into buckets in *reverse* order.
 
     Returns a list of buckets; each bucket is a list of ``(param_index, start, stop)`` element
     ranges (a parameter larger than ``split_large_bytes`` is cut into several ranges that land in
     separate buckets, so a 411 MB ``linear1.weight`` does not become one monolithic collective).
+
+    ``tail_cap_bytes``: the LAST bucket is the only one whose collective cannot hide under backward
+    (its final gradient — the first layer's — is the last thing backward produces).  When it is
+    larger than this cap, the parameters that become ready last (lowest indices) are split off into
+    a final bucket of at most ``tail_cap_bytes``: the exposed collective shrinks to a latency-sized
+    message and the rest of the old last bucket launches as soon as ITS last gradient is ready.
     """
     buckets, cur, cur_bytes = [], [], 0
     cap = first_cap_bytes
@@ -79,6 +85,16 @@ def plan_buckets(numels, elem_bytes, first_cap_bytes, cap_bytes, split_large_byt
         if cur_bytes >= cap:
             close()
     close()
+    if tail_cap_bytes and buckets and len(buckets[-1]) > 1:
+        last = buckets[-1]
+        if sum((e - s) * elem_bytes for _, s, e in last) > tail_cap_bytes:
+            tail, tail_bytes = [], 0
+            while len(last) > 1 and tail_bytes + (last[-1][2] - last[-1][1]) * elem_bytes <= tail_cap_bytes:
+                ent = last.pop()
+                tail.insert(0, ent)
+                tail_bytes += (ent[2] - ent[1]) * elem_bytes
+            if tail:
+                buckets.append(tail)
     return buckets
 
 
@@ -185,7 +201,7 @@ class TorchPGTransport(object):
 class BucketedReducer(object):
     def __init__(self, params, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
                  reduce_dtype=None, transport=None, flat_grad=None, flat_offsets=None,
-                 grad_dtype=None, shard_optimizer=None, bucket_align_elems=None):
+                 grad_dtype=None, shard_optimizer=None, bucket_align_elems=None, tail_bucket_mb=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("BucketedReducer needs at least one trainable parameter")
@@ -204,6 +220,10 @@ class BucketedReducer(object):
             first_bucket_mb = 8.0 if on_gpu else 1.0
         if split_large_mb is None:
             split_large_mb = 128.0 if on_gpu else 0.0
+        if tail_bucket_mb is None:
+            # VGG16: conv2_x + conv1_x = 0.5 MB of bf16 gradients end up alone in the exposed bucket,
+            # conv4_2 .. conv3_1 (9.5 MB) go out ~20 ms before backward ends
+            tail_bucket_mb = 1.0 if on_gpu else 0.0
         self.reduce_dtype = reduce_dtype
         self._core = None            # native bucket scheduler (C++), arena mode over the RCCL transport
         self._require_sync = True
@@ -222,7 +242,8 @@ class BucketedReducer(object):
         elem = torch.empty((), dtype=gdtype).element_size()
         numels = [p.numel() for p in self.params]
         plan = plan_buckets(numels, elem, int(first_bucket_mb * 2 ** 20), int(bucket_cap_mb * 2 ** 20),
-                            int(split_large_mb * 2 ** 20) if split_large_mb else None)
+                            int(split_large_mb * 2 ** 20) if split_large_mb else None,
+                            int(tail_bucket_mb * 2 ** 20) if tail_bucket_mb else None)
 
         self.buckets = []
         self._param_buckets = {}

@@ -106,6 +106,28 @@ def test_vgg16_bucket_plan_matches_survey():
     assert max(sizes) > 390                                  # linear1.weight dominates (411 MB fp32)
 
 
+def test_vgg16_gpu_bucket_plan_keeps_the_exposed_bucket_small():
+    """The GPU defaults (bf16 gradients, 8 / 16 / 128 MB caps, 1 MB tail): the LAST bucket — the only
+    collective that cannot hide under backward — holds just the two first blocks' gradients
+    (conv2_x + conv1_x, 0.5 MB); every parameter is still covered exactly once, in reverse order."""
+    m = VGG16(3, 3, False)
+    numels = [p.numel() for p in m.parameters()]
+    names = [n for n, _ in m.named_parameters()]
+    base = plan_buckets(numels, 2, 8 << 20, 16 << 20, 128 << 20)
+    plan = plan_buckets(numels, 2, 8 << 20, 16 << 20, 128 << 20, tail_cap_bytes=1 << 20)
+    assert len(plan) == len(base) + 1 and plan[:-2] == base[:-1]
+    assert plan[-2] + plan[-1] == base[-1]                      # the old last bucket, cut in two
+    tail_mb = sum(e - s for _, s, e in plan[-1]) * 2 / 2 ** 20
+    assert 0.3 < tail_mb <= 1.0, tail_mb
+    tail_names = [names[i] for i, _, _ in plan[-1]]
+    assert all(n.startswith(("backbone.0.", "backbone.1.")) for n in tail_names) and len(tail_names) == 8, tail_names
+    order = [i for b in plan for (i, _, _) in b]
+    assert order == sorted(order, reverse=True) and sorted(set(order)) == list(range(len(numels)))
+    # nothing to split: one-parameter last bucket, or a last bucket already under the cap
+    assert plan_buckets([10, 10], 4, 1, 1, tail_cap_bytes=16) == plan_buckets([10, 10], 4, 1, 1)
+    assert plan_buckets([10, 10, 10], 4, 1000, 1000, tail_cap_bytes=1000) == plan_buckets([10, 10, 10], 4, 1000, 1000)
+
+
 # ------------------------------------------------------------------------------------ model / state_dict
 def _stock_vgg16(out_channels=3):
     """Independent torch.nn re-statement of the reference architecture (model/vgg16.py) used to
