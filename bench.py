@@ -85,8 +85,11 @@ def main(argv=None):
     # version banner and WARN lines, gloo's "Rank 0 is connected to ..." notices), so file descriptor 1
     # points at stderr for the duration of the run and is restored for the result line.
     sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+    try:
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+    except OSError:                 # no usable stdout / stderr descriptor: leave the streams as they are
+        real_stdout = None
     if os.environ.get("DTP_BENCH_DUMP_AFTER"):      # debugging aid: dump every thread's stack and exit
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["DTP_BENCH_DUMP_AFTER"]), exit=True)
@@ -213,7 +216,8 @@ def main(argv=None):
         info = getattr(tr, "info", None) or {}
         plain = not (args.batch_norm or args.fp8_classifier)
         sys.stdout.flush()
-        os.dup2(real_stdout, 1)
+        if real_stdout is not None:
+            os.dup2(real_stdout, 1)
         print(json.dumps({
             "metric": "train images/sec (whole node) VGG16 bf16 224px",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -246,8 +250,10 @@ def main(argv=None):
                        "grad_dtype": args.grad_dtype if on_gpu else "fp32", "grad_accum": args.grad_accum,
                        "fp8_classifier": bool(args.fp8_classifier), "backend": backend,
                        "grad_transport": type(tr).__name__}}), flush=True)
-        os.dup2(2, 1)                       # teardown chatter (communicator destruction) stays off stdout
-    os.close(real_stdout)
+        if real_stdout is not None:
+            os.dup2(2, 1)                   # teardown chatter (communicator destruction) stays off stdout
+    if real_stdout is not None:
+        os.close(real_stdout)
     if on_gpu:
         torch.cuda.synchronize()
     if hasattr(data, "close"):
