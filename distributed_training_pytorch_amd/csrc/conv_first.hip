@@ -241,6 +241,14 @@ struct Conv1WgradParams {
   const float* mask_bias;   // [64] or null
 };
 
+// XOR swizzle (in 16-byte chunks) of the weight-gradient kernel's 64-byte-row LDS images.  Found by
+// exhaustive search over the GF(2)-linear maps of the low four row bits against the lane groups of
+// MI355X_MICROARCH.md's LDS table: conflict-free for (i) the ds_read_b128 fragment reads of the
+// self-masking forward, (ii) the ds_write_b128 of the image rows and (iii) the transposed
+// ds_read_b64_tr_b16 reads of the gradient MFMAs, whose 16-lane groups sit 8 rows apart — the
+// forward kernel's (row >> 1) & 3 satisfies (i) and (ii) only (2-way conflicts on (iii)).
+DTP_DEVINL int s64w(int row) { return ((row >> 2) & 1) | ((((row >> 1) ^ (row >> 2) ^ (row >> 3)) & 1) << 1); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams p) {
   // LDS: dY image [256 px][64] bf16 (128-B rows, tr-read swizzle) 32 KiB | A image [256 px][32 k] bf16
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
       const uint32_t hi = k0 + 1 < K ? p.mask_w[row * K + k0 + 1] : 0;
       qv[e] = lo | (hi << 16);
     }
-    *(u32x4_t*)(lW + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = qv;
+    *(u32x4_t*)(lW + row * 64 + ((ch ^ s64w(row)) << 4)) = qv;
   }
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -306,7 +314,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
       v[27] = (m0 + tid < p.c.M) ? 1.f : 0.f;
 #pragma unroll
       for (int k = 28; k < 32; ++k) v[k] = 0.f;
-      const int sw = (tid >> 1) & 3;
+      const int sw = s64w(tid);
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch) {
         u32x4_t qv;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
       // y = W * im2col + b for this wave's 64 pixels; zero dY (in its LDS image) where y <= 0.
       // The wave masks exactly the rows it reads below, so a wave-level fence is enough.
       const int fr = lane & 15, fk = lane >> 4;
-      const int foff = fr * 64 + ((fk ^ ((fr >> 1) & 3)) << 4);
+      const int foff = fr * 64 + ((fk ^ s64w(fr)) << 4);
       const int cq = fk * 4;
       bf16x8_t xf[4], wf[4];
 #pragma unroll
@@ -374,8 +382,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const Conv1WgradParams
 #pragma unroll
       for (int j = 0; j < 2; ++j) {   // lane li: im2col index j*16 + li, pixels px0 + 8*g4 + 0..7
         const int r0 = px0 + krow, r1 = r0 + 4;
-        const char* b0 = lA + r0 * 64 + (((2 * j + sub) ^ ((r0 >> 1) & 3)) << 4) + half8;
-        const char* b1 = lA + r1 * 64 + (((2 * j + sub) ^ ((r1 >> 1) & 3)) << 4) + half8;
+        const char* b0 = lA + r0 * 64 + (((2 * j + sub) ^ s64w(r0)) << 4) + half8;
+        const char* b1 = lA + r1 * 64 + (((2 * j + sub) ^ s64w(r1)) << 4) + half8;
         s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(b0));
         s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(b1));
         bf[j] = (bf16x8_t){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
