@@ -345,7 +345,12 @@ def bring_up(device, want="auto"):
     """
     info = dict(requested=want, kind="torch", fell_back=False, reason=None)
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
-    timeout_s = float(os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", "180"))
+    # Under the self-launcher (it exports DTP_RESTART_COUNT) a bring-up that does not finish is answered
+    # by a relaunch on the process-group transport, so the deadline is short.  Under any other launcher
+    # (torchrun: the driver's N > 1 bench runs) nobody relaunches — a late communicator beats a dead
+    # job, so wait almost as long as the process group itself would (DTP_PG_TIMEOUT_S, 600 s).
+    default_timeout = "180" if "DTP_RESTART_COUNT" in os.environ else "480"
+    timeout_s = float(os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", default_timeout))
     ok, payload, n, err = 1.0, b"", 0, None
     try:
         rt = _rt()
