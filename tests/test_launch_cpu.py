@@ -44,12 +44,37 @@ def test_bench_self_launches_two_fresh_workers_cpu():
     assert j2["final_loss"] == j["final_loss"]                  # world 2: the same sums in the same order
 
 
+DRIVER_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+               "vs_baseline", "dtype", "data", "config")
+
+
+def test_bench_under_torch_distributed_run_cpu():
+    """The driver's N > 1 launch: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`` — ranks come from
+    the environment, rank 0 prints the result, and stdout carries NOTHING else (gloo's connection
+    notices and RCCL's banner go to stderr)."""
+    from distributed_training_pytorch_amd.launch import free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu",
+           "--batch-per-gpu", "4", "--image-size", "32", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-3000:]                    # ONE line on stdout, the JSON
+    j = json.loads(lines[0])
+    assert all(k in j for k in DRIVER_KEYS), sorted(j)
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 2 and j["warmup"] == 1
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["config"]["global_batch"] == 8
+    assert j["grad_transport_selfcheck_ok"] is True
+
+
 def test_bench_single_process_path_is_unchanged_cpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--batch-per-gpu", "2",
                         "--image-size", "32", "--steps", "1", "--warmup", "1"], cwd=ROOT, env=ENV,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)
+    assert len([l for l in r.stdout.splitlines() if l.strip()]) == 1 and all(k in j for k in DRIVER_KEYS)
     assert j["n_gpus"] == 1 and j["ranks_seen"] == 1 and j["config"]["parallelism"] == "dp1"
     # WORLD_SIZE says 1 but --gpus says 2: refuse instead of benchmarking the wrong job
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu"], cwd=ROOT,
