@@ -252,6 +252,12 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #define C64_RD(i) DTP_DSR128(xf[((i) / 4) & 1][(i) % 4], (sl[(i) / 12] + xo[((i) / 4) % 3]) ^ (((i) % 4) << 5));
     C64_RD(0) C64_RD(1) C64_RD(2) C64_RD(3)
     f32x16_t acc;
+#ifdef DTP_C64_PROBE16
+    // DIAGNOSTIC ONLY (wrong results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same
+    // operand registers — same LDS traffic, same matrix cycles — to see whether the chip holds a
+    // higher clock under the 16x16x32 shape in this loop (MI355X_MICROARCH.md, DVFS give-back item 7)
+    f32x4_t accq[4];
+#endif
     // (a macro per step, not a `#pragma unroll` loop: hipcc left the loop rolled and sent the
     // filter registers to scratch)
     // LDS ops younger than read i when MFMA i issues: reads i+1 .. i+3, and for i = 2 .. 5 the ND
@@ -262,18 +268,30 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #else
 #define C64_SB
 #endif
+#ifdef DTP_C64_PROBE16
+#define C64_ACC_INIT(q, e) accq[q][e]
+#define C64_MMA(i)                                                                                             \
+    accq[((i) & 1) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                             \
+        wf[(i) / 4][(i) % 4], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), accq[((i) & 1) * 2], 0, 0, 0);     \
+    accq[((i) & 1) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                         \
+        wf[(i) / 4][(i) % 4], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), accq[((i) & 1) * 2 + 1], 0, 0, 0);
+#else
+#define C64_ACC_INIT(q, e) acc[(q) * 4 + (e)]
+#define C64_MMA(i)                                                                                             \
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(i) / 4][(i) % 4],                                        \
+                                                  __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), acc, 0, 0, 0);
+#endif
 #define C64_STEP(i)                                                                                          \
   {                                                                                                          \
     if ((i) == 0) {                                                                                          \
       asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xf[0][0]), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3])); \
       _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int e = 0; e < 4; ++e)            \
-          acc[q * 4 + e] = __uint_as_float(bq[q][e]);                                                        \
+          C64_ACC_INIT(q, e) = __uint_as_float(bq[q][e]);                                                    \
     } else {                                                                                                 \
       asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(xf[((i) / 4) & 1][(i) % 4]) : "n"(C64_YOUNG(i)));          \
     }                                                                                                        \
     C64_SB                                                                                                   \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[(i) / 4][(i) % 4],                                      \
-                                                  __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), acc, 0, 0, 0); \
+    C64_MMA(i)                                                                                               \
     C64_SB                                                                                                   \
     if ((i) + 4 < 36) { C64_RD(((i) + 4 < 36 ? (i) + 4 : 0)) }                                               \
     if ((i) == 1) {                                                                                          \
@@ -320,6 +338,12 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #undef C64_STEP
 #undef C64_YOUNG
 #undef C64_RD
+#undef C64_MMA
+#undef C64_ACC_INIT
+#ifdef DTP_C64_PROBE16
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = accq[k / 4][k % 4];
+#endif
     C64_STAMP(3)
     // ---- the finished row: (+ earlier partial sums) -> bf16 -> ReLU -> parked in the row buffer
     if (!POOL && p.acc_src && (w0 + l31) < p.W) {
