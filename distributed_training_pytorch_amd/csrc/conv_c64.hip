@@ -21,6 +21,16 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
+// MFMA shape of the row step.  1 (default): v_mfma_f32_16x16x32_bf16 — a 32 px x 32 cout block is four
+// 16x16 accumulators, one B-fragment read (16 px x 32 channels) feeds two MFMAs (cout halves), so LDS
+// bytes, matrix cycles and the 144 filter registers are those of the 32x32x16 form (0, kept for A/B:
+// -DDTP_C64_MFMA16=0), but the chip holds a higher clock under this shape (MI355X_MICROARCH.md "DVFS
+// give-back" item 7; probed here at +3.5-5 % before the conversion).  Only the lane -> (pixel, channel)
+// maps of the operands and of the accumulator differ; everything behind the parked row buffer is shared.
+#ifndef DTP_C64_MFMA16
+#define DTP_C64_MFMA16 1
+#endif
+
 struct ConvC64Params {
   const char* X;         // [N*H*W][ldx] bf16: the 64 reduction channels are a 128-byte slice of each pixel row
   const char* acc_src;   // optional [N*H*W][O] bf16 added to the accumulator (may alias out): lets a
@@ -43,6 +53,15 @@ struct ConvC64Params {
 // LDS ops the compiler does not track (counted waits, see dtp_common.h DTP_DSR128)
 #define C64_DSW64(addr, data) asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(data) : "memory")
 #define C64_NAME2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+// XOR swizzle (16-byte chunks) of ring position pos: conflict-free for the lane groups of ds_read_b128
+// under the fragment geometry in use (bench/lds_bank_sim.py model; the 32-row reads of the 32x32x16
+// form want (pos >> 1) & 7, the 16-row reads of the 16x16x32 form pos & 6 — with the former they
+// would conflict 2-way at dx = 0, +1)
+#if DTP_C64_MFMA16
+#define C64_SWZ(pos) ((pos) & 6)
+#else
+#define C64_SWZ(pos) (((pos) >> 1) & 7)
+#endif
 #define C64_NAME4(a, b, c, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
 // Row step = 36 MFMAs on ONE accumulator chain.  In-kernel stamps (bench/stamp_c64.py) showed a wave
@@ -74,6 +93,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hb = lane >> 5;
+  const int l15 = lane & 15, g4 = lane >> 4;      // 16x16x32 operand / accumulator geometry
 
   // ---- work item
   const int chunk = blockIdx.x;
@@ -89,11 +109,22 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   // ---- this wave's filter slice -> registers: A operand, lane = (row cout = l31, k = 8*hb + j)
   bf16x8_t wf[9][4];
   {
+#if DTP_C64_MFMA16
+    // wf[t][2*ch + oh]: tap t, channel half ch (32 channels = one K step), cout half oh;
+    // lane = (row cout = 16*oh + l15, k = 8*g4 + j)
+    const char* wbase = p.Wt + ((size_t)(wave * 32 + l15) * 576 + 8 * g4) * 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        wf[t][k] = *(const bf16x8_t*)(wbase + ((size_t)(k & 1) * 16 * 576 + t * 64 + (k >> 1) * 32) * 2);
+#else
     const char* wbase = p.Wt + ((size_t)(wave * 32 + l31) * 576 + 8 * hb) * 2;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
       for (int k = 0; k < 4; ++k) wf[t][k] = *(const bf16x8_t*)(wbase + (t * 64 + k * 16) * 2);
+#endif
   }
   if (tid < O) lBias[tid] = p.bias ? p.bias[tid] : 0.f;
 
@@ -117,7 +148,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   for (int k = 0; k < PW; ++k) {
     const int pos = (wave + k * NW) * 8 + (lane >> 3);
     const int w = w0 - 1 + pos;
-    const int lc = (lane & 7) ^ ((pos >> 1) & 7);
+    const int lc = (lane & 7) ^ C64_SWZ(pos);
     xcol[k] = (pos < 34 && w >= 0 && w < p.W) ? (unsigned)((w * p.ldx + lc * 8) * 2) : BAD;
   }
   const unsigned x_row_bytes = (unsigned)(p.W * p.ldx * 2);
@@ -130,19 +161,40 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
   // fragment read geometry: B operand, lane = (col px = l31, k = 8*hb + j); ring position px+dx+1
   // byte offset of fragment k at ring position pos = l31 + d: pos*128 + (((2k + hb) ^ ((pos>>1)&7)) << 4)
   //   = xo[d] ^ (k << 5)   (2k only touches chunk bits 1..2): three registers instead of twelve
+#if DTP_C64_MFMA16
+  // 16x16x32: B operand, lane = (col px = 16*ph + l15, k = 8*g4 + j of channel half ch); fragment
+  // (ph, ch) at ring position pos = 16*ph + l15 + d: pos*128 + (((4*ch + g4) ^ swz(pos)) << 4)
+  //   = xo[ph][d] ^ (ch << 6)
+  int xo[2][3];
+#pragma unroll
+  for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int pos = 16 * ph + l15 + d;
+      xo[ph][d] = pos * 128 + ((g4 ^ C64_SWZ(pos)) << 4);
+    }
+#else
   int xo[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int pos = l31 + d;
-    xo[d] = pos * 128 + ((hb ^ ((pos >> 1) & 7)) << 4);
+    xo[d] = pos * 128 + ((hb ^ C64_SWZ(pos)) << 4);
   }
+#endif
   const unsigned lx0 = lds_addr(lX);
   const unsigned myO = lds_addr(lO + wave * 4096);
   // accumulator register 4q + e = cout 8q + 4hb + e of pixel l31: bias as four 16-byte LDS reads
-  const unsigned bias_a = lds_addr(lBias) + (wave * 32 + 4 * hb) * 4;
   // row buffer: pixel px = 64 bytes = four 16-byte chunks (8 couts), chunk c stored at c ^ ((px >> 2) & 3)
+#if DTP_C64_MFMA16
+  // accumulator (oh, ph)[e] = cout 16*oh + 4*g4 + e of pixel 16*ph + l15: bias as two 16-byte LDS reads
+  const unsigned bias_a = lds_addr(lBias) + (wave * 32 + 4 * g4) * 4;
+  const unsigned wr_a = myO + l15 * 64 + (g4 & 1) * 8;          // + ph * 1024; chunk 2*oh + (g4 >> 1)
+  const int wr_sw = (l15 >> 2) & 3;
+#else
+  const unsigned bias_a = lds_addr(lBias) + (wave * 32 + 4 * hb) * 4;
   const unsigned wr_a = myO + l31 * 64 + hb * 8;
   const int wr_sw = (l31 >> 2) & 3;
+#endif
   // deferred read-back geometry
   //   !POOL: lane = (px = lane/4 + 16r, chunk = lane%4): one 16-byte row segment per read / store
   //   POOL:  lane = (pooled px pp = lane/4, chunk = lane%4): pixels 2pp, 2pp+1 of both row buffers
@@ -247,16 +299,21 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
     for (int d = 0; d < 3; ++d) sl[d] = lx0 + ((h + d) & 3) * X_SLOT;    // rows h-1, h, h+1
     u32x4_t bq[4], xf[2][4];
     __builtin_amdgcn_sched_barrier(0);
+#if DTP_C64_MFMA16
+    // read i of a tap (i % 4): pixel half ph = i & 1, channel half ch = (i >> 1) & 1
+    DTP_DSR128(bq[0], bias_a);
+    DTP_DSR128(bq[1], bias_a + 64);
+    DTP_DSR128(bq[2], bias_a);            // (bq[2], bq[3]: the counted waits below assume four bias reads)
+    DTP_DSR128(bq[3], bias_a + 64);
+#define C64_RD(i) DTP_DSR128(xf[((i) / 4) & 1][(i) % 4], (sl[(i) / 12] + xo[(i) & 1][((i) / 4) % 3]) ^ ((((i) >> 1) & 1) << 6));
+    C64_RD(0) C64_RD(1) C64_RD(2) C64_RD(3)
+    f32x4_t acc4[2][2];                   // [cout half oh][pixel half ph]
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) DTP_DSR128(bq[q], bias_a + q * 32);
 #define C64_RD(i) DTP_DSR128(xf[((i) / 4) & 1][(i) % 4], (sl[(i) / 12] + xo[((i) / 4) % 3]) ^ (((i) % 4) << 5));
     C64_RD(0) C64_RD(1) C64_RD(2) C64_RD(3)
     f32x16_t acc;
-#ifdef DTP_C64_PROBE16
-    // DIAGNOSTIC ONLY (wrong results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same
-    // operand registers — same LDS traffic, same matrix cycles — to see whether the chip holds a
-    // higher clock under the 16x16x32 shape in this loop (MI355X_MICROARCH.md, DVFS give-back item 7)
-    f32x4_t accq[4];
 #endif
     // (a macro per step, not a `#pragma unroll` loop: hipcc left the loop rolled and sent the
     // filter registers to scratch)
@@ -268,13 +325,13 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #else
 #define C64_SB
 #endif
-#ifdef DTP_C64_PROBE16
-#define C64_ACC_INIT(q, e) accq[q][e]
+#if DTP_C64_MFMA16
+#define C64_ACC_INIT(q, e) acc4[(q) & 1][(q) >> 1][e]      /* bq[q] = bias quad of cout half q & 1 */
 #define C64_MMA(i)                                                                                             \
-    accq[((i) & 1) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                             \
-        wf[(i) / 4][(i) % 4], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), accq[((i) & 1) * 2], 0, 0, 0);     \
-    accq[((i) & 1) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                         \
-        wf[(i) / 4][(i) % 4], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), accq[((i) & 1) * 2 + 1], 0, 0, 0);
+    acc4[0][(i) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                \
+        wf[(i) / 4][(((i) >> 1) & 1) * 2], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), acc4[0][(i) & 1], 0, 0, 0); \
+    acc4[1][(i) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                                \
+        wf[(i) / 4][(((i) >> 1) & 1) * 2 + 1], __builtin_bit_cast(bf16x8_t, xf[((i) / 4) & 1][(i) % 4]), acc4[1][(i) & 1], 0, 0, 0);
 #else
 #define C64_ACC_INIT(q, e) acc[(q) * 4 + (e)]
 #define C64_MMA(i)                                                                                             \
@@ -331,7 +388,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
     // deferred epilogue and of the read addresses, 24 times
 #pragma unroll
     for (int g = 0; g < 24; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, DTP_C64_MFMA16 ? 2 : 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, POOL ? 8 : (MASK ? 8 : 5), 0);
       __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
     }
@@ -340,12 +397,57 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
 #undef C64_RD
 #undef C64_MMA
 #undef C64_ACC_INIT
-#ifdef DTP_C64_PROBE16
-#pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = accq[k / 4][k % 4];
-#endif
     C64_STAMP(3)
     // ---- the finished row: (+ earlier partial sums) -> bf16 -> ReLU -> parked in the row buffer
+    if constexpr (!POOL) {
+      // The run-time acc_src branch below ends the basic block right behind the last MFMA, and hipcc
+      // (ROCm 7.2) left the first accumulator read behind that branch 2 wait states after an MFMA
+      // that needs 11 (8 passes + 3): on the GPU the last tap's product was missing from the first
+      // packed pair of every row whose row h+1 is not zero.  The POOL kernels have no branch here
+      // and get the compiler's own s_nops.  Cover the hazard by hand where the branch is.
+#if DTP_C64_MFMA16
+      asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc4[0][0]), "+v"(acc4[0][1]), "+v"(acc4[1][0]), "+v"(acc4[1][1]));
+#else
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));
+#endif
+    }
+#if DTP_C64_MFMA16
+    if (!POOL && p.acc_src) {
+      // two-pass 128-channel reduction (opt-in): accumulator (oh, ph)[e] = cout 16*oh + 4*g4 + e of pixel 16*ph + l15
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        if ((w0 + 16 * ph + l15) < p.W) {
+          const char* ap = p.acc_src + ((img_px + (size_t)h * p.W + w0 + 16 * ph + l15) * O + wave * 32 + 4 * g4) * 2;
+#pragma unroll
+          for (int oh = 0; oh < 2; ++oh) {
+            const u32x2_t pv = *(const u32x2_t*)(ap + oh * 32);
+            acc4[oh][ph][0] += __uint_as_float(pv[0] << 16);
+            acc4[oh][ph][1] += __uint_as_float(pv[0] & 0xFFFF0000u);
+            acc4[oh][ph][2] += __uint_as_float(pv[1] << 16);
+            acc4[oh][ph][3] += __uint_as_float(pv[1] & 0xFFFF0000u);
+          }
+        }
+      }
+    }
+    {
+      typedef short s16x2_t __attribute__((ext_vector_type(2)));
+      const bool relu = POOL || p.relu;
+      const unsigned buf = POOL ? (unsigned)((h - h0) & 1) * 2048u : 0u;
+#pragma unroll
+      for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+          const f32x4_t a = acc4[oh][ph];
+          uint32_t lo = pack_bf16x2(a[0], a[1]), hi = pack_bf16x2(a[2], a[3]);
+          if (relu) {   // round(relu(x)) == relu(round(x)): packed signed-16-bit max on the bf16 bit patterns
+            lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, lo), (s16x2_t){0, 0}));
+            hi = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, hi), (s16x2_t){0, 0}));
+          }
+          const u32x2_t pk = {lo, hi};
+          C64_DSW64(wr_a + buf + ph * 1024 + (((2 * oh + (g4 >> 1)) ^ wr_sw) << 4), pk);
+        }
+    }
+#else
     if (!POOL && p.acc_src && (w0 + l31) < p.W) {
       // two-pass 128-channel reduction (opt-in): register r = cout 8*(r>>2) + 4*hb + (r&3) of pixel l31
       const char* ap = p.acc_src + ((img_px + (size_t)h * p.W + w0 + l31) * O + wave * 32 + 4 * hb) * 2;
@@ -373,6 +475,7 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
         C64_DSW64(wr_a + buf + ((q ^ wr_sw) << 4), pk);
       }
     }
+#endif
     C64_STAMP(4)
   }
   // ---- flush the last parked row / row pair
