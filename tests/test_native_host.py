@@ -23,3 +23,15 @@ def test_rccl_transport_host_logic_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=env)
     assert r.returncode == 0 and "transport host test ok" in r.stdout, r.stdout[-4000:]
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_no_mfma_result_is_read_too_early_in_the_shipped_kernels():
+    """Static check of the gfx950 assembly (bench/check_mfma_hazards.py): no MFMA result is read or
+    overwritten by a non-MFMA instruction fewer wait states later than the matrix pipe needs, along
+    fall-through AND branch paths.  hipcc's own hazard cover stopped at a branch behind the last MFMA
+    of conv_c64's row step once (wrong sums on the GPU, nothing at compile time, docs/KERNELS.md)."""
+    r = subprocess.run(["python", os.path.join(ROOT, "bench", "check_mfma_hazards.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "conv_c64.hip" in r.stdout and "igemm.hip" in r.stdout
