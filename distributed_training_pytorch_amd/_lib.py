@@ -51,6 +51,7 @@ _SIGS = {
                         c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p],
     "dtp_cast_f32_bf16": [c_void_p, c_void_p, c_size_t, c_void_p],
     "dtp_relu_mask": [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p],
+    "dtp_stream_delay": [c_float, c_void_p],
     "dtp_softmax_xent": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_int, c_float, c_float, c_void_p],
     "dtp_bn_fwd_train": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,

@@ -274,6 +274,26 @@ extern "C" int dtp_relu_mask(const void* g, const void* y, void* out, size_t n, 
   return DTP_CHECK_LAUNCH();
 }
 
+// ------------------------------------------------------------------------------------ stream delay
+// One wave that does nothing for `us` microseconds (100 MHz wall clock, s_sleep between polls; the
+// loop ends when time has passed, whatever else happens).  Used to give a PERSISTENT kernel on
+// another stream a head start before this stream's next kernel is dispatched: when conv_c64's data
+// gradient (2 waves / workgroup, 220 VGPRs) reaches the CUs first it keeps refilling every slot it
+// frees, the 4-wave workgroups of wgrad_c64's persistent grid do not fit the 2-wave holes and start
+// only when the data gradient has drained — and then each still does its full static share
+// (measured in the VGG16-BN step: 7.8 ms for the pair instead of 6.0, docs/KERNELS.md).
+__global__ __launch_bounds__(64) void stream_delay_kernel(unsigned ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int dtp_stream_delay(float us, hipStream_t s) {
+  if (!(us > 0.f)) return 0;
+  if (us > 1000.f) return -10;                       // a head start, not a timer
+  hipLaunchKernelGGL(stream_delay_kernel, dim3(1), dim3(64), 0, s, (unsigned)(us * 100.f));
+  return DTP_CHECK_LAUNCH();
+}
+
 // ------------------------------------------------------------------------------------ fp8 (OCP e4m3) quantisation
 // Per-tensor scaling for the fp8 classifier GEMMs (BASELINE.json config 5): amax -> scale = amax/448
 // -> q = e4m3(x / scale).  Two-pass deterministic amax (no float atomics); everything stays on the

@@ -773,6 +773,22 @@ def cast_f32_bf16(src, dst):
     return dst
 
 
+# head start (microseconds) for wgrad_c64's persistent grid before the data gradient of the same layer
+# is dispatched on the other stream (csrc/eltwise.hip stream_delay_kernel); 0 = off
+wgrad_head_start_us = float(_os.environ.get("DTP_WGRAD_HEAD_START_US", "20"))
+
+
+def wgrad_is_persistent(C, Co):
+    """True when ``conv3x3_wgrad`` takes the persistent-grid kernel (wgrad_c64)."""
+    return C == 64 and Co in (64, 128) and "wgrad" not in _overrides
+
+
+def stream_delay(us):
+    """Keep the current stream busy with nothing for ``us`` microseconds (one idle wave)."""
+    if us > 0:
+        check(_lib.hip().dtp_stream_delay(float(us), stream()), "stream_delay")
+
+
 def relu_mask(g, y, scale=1.0, out=None):
     _need(g, BF16, "g")
     _need(y, BF16, "y")

@@ -164,6 +164,8 @@ class _Conv3x3Fn(torch.autograd.Function):
             # tiles (conv5: 196 tiles on 256 CUs) is filled by the other's workgroups
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+            if K.wgrad_is_persistent(x.shape[3], Co):
+                K.stream_delay(K.wgrad_head_start_us)     # the persistent grid must be resident first
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         if ctx.has_bias:
@@ -210,6 +212,8 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         if side is not None:
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
+            if K.wgrad_is_persistent(Ci, Co):
+                K.stream_delay(K.wgrad_head_start_us)
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))

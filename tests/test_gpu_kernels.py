@@ -901,3 +901,22 @@ def test_vgg_classifier_shapes_through_the_production_pickers(shape):
     dx = k.linear_dgrad(dy, wt)
     refdx = dy.float()[:, :Nout] @ w.float()
     _close(dx, refdx, 2e-2, 2e-2 * refdx.abs().max().item(), "fc dgrad %s" % (shape,))
+
+
+def test_stream_delay_holds_the_stream_for_about_the_requested_time():
+    """stream_delay (the head start wgrad_c64's persistent grid gets before the data gradient is
+    dispatched): one idle wave, bounded, and it ends by itself."""
+    k = _k()
+    k.stream_delay(50.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    k.stream_delay(500.0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    assert 0.4 < ms < 5.0, ms
+    k.stream_delay(0.0)                     # off: no launch
+    with pytest.raises(Exception):
+        k.stream_delay(5000.0)              # a head start, not a timer
+    assert k.wgrad_is_persistent(64, 64) and k.wgrad_is_persistent(64, 128) and not k.wgrad_is_persistent(128, 128)
