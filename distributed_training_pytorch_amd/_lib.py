@@ -26,12 +26,12 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
 _SIGS = {
     "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p],
+                     c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],
     "dtp_conv_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_int, c_void_p, c_void_p],
+                     c_float, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dtp_wgrad_c64": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_float, c_void_p],
     "dtp_maxpool2x2_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
@@ -55,13 +55,13 @@ _SIGS = {
     "dtp_softmax_xent": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                          c_int, c_float, c_float, c_void_p],
     "dtp_bn_fwd_train": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int,
-                         c_float, c_float, c_int, c_void_p],
+                         c_float, c_float, c_int, c_void_p, c_int, c_void_p],
     "dtp_bn_fwd_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float,
                         c_int, c_void_p],
     "dtp_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
                    c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "dtp_bn_fwd_train_pool": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_int, c_int, c_int, c_int, c_float, c_float, c_void_p],
+                              c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p],
     "dtp_bn_bwd_pool": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                         c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_sgd_flat": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,

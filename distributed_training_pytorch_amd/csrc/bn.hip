@@ -392,6 +392,30 @@ int bn_grid(long M, int C) {
   return (int)blocks;
 }
 
+// Producer-side statistics: the convolution in front of this BatchNorm left (sum y, sum y^2) per
+// output tile ([ntiles][2][C], igemm.hip colsum_sq) — fold groups of consecutive tile rows into at
+// most BN_MAXBLK partial rows (fixed order: deterministic) for bn_finalize_kernel; the pass over y
+// that bn_reduce_kernel<0> makes is not needed then.
+__global__ __launch_bounds__(256) void bn_fold_tiles_kernel(const float* __restrict__ tp, int ntiles, int per, int C,
+                                                            float* __restrict__ partial) {
+  const int r0 = blockIdx.x * per;
+  int r1 = r0 + per;
+  if (r1 > ntiles) r1 = ntiles;
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += tp[(size_t)r * 2 * C + c];
+    partial[(size_t)blockIdx.x * 2 * C + c] = s;
+  }
+}
+
+// -> number of partial rows written
+int bn_fold_tiles(const float* tp, int ntiles, int C, float* partial, hipStream_t s) {
+  const int per = (ntiles + BN_MAXBLK - 1) / BN_MAXBLK;
+  const int nblk = (ntiles + per - 1) / per;
+  hipLaunchKernelGGL(bn_fold_tiles_kernel, dim3(nblk), dim3(256), 0, s, tp, ntiles, per, C, partial);
+  return nblk;
+}
+
 bool bn_shape_ok(long M, int C) { return M > 0 && C >= 64 && C <= 512 && (C & (C - 1)) == 0; }
 
 }  // namespace
@@ -399,12 +423,16 @@ bool bn_shape_ok(long M, int C) { return M > 0 && C >= 64 && C <= 512 && (C & (C
 // partial: >= 1024 * 2 * C floats.  stats (4 x C floats): mean | rstd | scale | shift.
 extern "C" int dtp_bn_fwd_train(const void* y, void* z, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, float* stats, float* partial, long M, int C, float eps,
-                                float momentum, int relu, hipStream_t s) {
+                                float momentum, int relu, const float* tile_partial, int ntiles, hipStream_t s) {
   if (!bn_shape_ok(M, C)) return -10;
-  const int nblk = bn_grid(M, C);
+  if (tile_partial && ntiles < 1) return -11;
+  int nblk = bn_grid(M, C);
   float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, partial, M, C, relu);
+  if (tile_partial)
+    nblk = bn_fold_tiles(tile_partial, ntiles, C, partial, s);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, partial, M, C, relu);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, eps, momentum, gamma,
                      beta, mean, rstd, scale, shift, running_mean, running_var);
   const long nvec = M * (C >> 3);
@@ -469,14 +497,19 @@ static int bn_pool_grid(const PoolGeom& gm) {
 // zp: [N][H/2][W/2][C] bf16, codes: [N][H/2][W/2][C/8] uint32; stats / partial as dtp_bn_fwd_train
 extern "C" int dtp_bn_fwd_train_pool(const void* y, void* zp, void* codes, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float* stats, float* partial, int N,
-                                     int H, int W, int C, float eps, float momentum, hipStream_t s) {
+                                     int H, int W, int C, float eps, float momentum, const float* tile_partial,
+                                     int ntiles, hipStream_t s) {
   PoolGeom gm;
   if (!bn_pool_geom(gm, N, H, W, C)) return -10;
+  if (tile_partial && ntiles < 1) return -11;
   const long M = (long)N * H * W;
-  const int nblk = bn_grid(M, C);
+  int nblk = bn_grid(M, C);
   float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, partial, M, C, 1);
+  if (tile_partial)
+    nblk = bn_fold_tiles(tile_partial, ntiles, C, partial, s);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, partial, M, C, 1);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, eps,
                      momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
   hipLaunchKernelGGL(bn_apply_pool_kernel, dim3(2 * bn_pool_grid(gm)), dim3(BN_T), 0, s, (const u32x4_t*)y,

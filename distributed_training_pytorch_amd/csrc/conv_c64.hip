@@ -47,6 +47,8 @@ struct ConvC64Params {
   int S, RC, rows_per_chunk;
   int relu;
   float mask_scale;
+  float* stats_part;     // STATS kernels: [gridDim.x][2][O] f32 (sum y, sum y^2) of this workgroup's stored outputs —
+                         // the batch statistics of a BatchNorm that follows (bn.hip partial layout)
   unsigned long long* stamps;   // DEBUG (DTP_C64_STAMPS): per workgroup, first 16 row steps x 6 stamps (bench/stamp_c64.py)
 };
 
@@ -78,8 +80,9 @@ struct ConvC64Params {
 //   * the workgroup barrier sits after tap 2 (the last read of ring row h-1): the LDS-DMA of row
 //     h+3 that follows it has two row steps to land, and the deferred stores issued right after it
 //     are a full step old when the next `vmcnt(0)` comes.
-template <int O, bool POOL, bool MASK>
+template <int O, bool POOL, bool MASK, bool STATS = false>
 __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params p) {
+  static_assert(!STATS || (!POOL && !MASK), "statistics come out of the plain store epilogue");
   constexpr int NW = O / 32;             // waves per workgroup (2 or 4)
   constexpr int PW = NW == 2 ? 3 : 2;    // LDS-DMA pieces (8 ring positions, 1 KiB) per wave and row
   constexpr int X_SLOT = PW * NW * 1024; // 48 / 64 ring positions: 34 used, the rest take hardware zeros
@@ -229,12 +232,25 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
     }
   };
   // !POOL: the parked row -> global (mask, 1-bit masks); st[] complete (see the callers)
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // STATS
   auto deferred_store = [&](unsigned row_off) {
     C64_NAME2(st[0], st[1]);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       u32x4_t v = st[r];
       const unsigned off = ocol[r] + row_off;
+      if constexpr (STATS) {
+        // only what is really stored counts: strip tail (ocol BAD) and "nothing parked" (row BAD) are dropped
+        const uint32_t keep = (ocol[r] < BAD && row_off < BAD) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float((v[e] << 16) & keep), hi = __uint_as_float(v[e] & 0xFFFF0000u & keep);
+          cs[2 * e] += lo;
+          cs[2 * e + 1] += hi;
+          cq[2 * e] = fmaf(lo, lo, cq[2 * e]);
+          cq[2 * e + 1] = fmaf(hi, hi, cq[2 * e + 1]);
+        }
+      }
       if constexpr (MASK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -493,13 +509,33 @@ __global__ __launch_bounds__(O * 2, 2) void conv_c64_kernel(const ConvC64Params 
       pool_store(last_off);
     }
   }
+  if constexpr (STATS) {
+    // lanes with the same chunk (lane & 3) hold the same 8 couts of different pixels: fold lane bits 2..5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = 4; m < 64; m <<= 1) {
+        cs[e] += __shfl_xor(cs[e], m);
+        cq[e] += __shfl_xor(cq[e], m);
+      }
+    }
+    if (lane < 4) {
+      float* row = p.stats_part + (size_t)blockIdx.x * 2 * O + wave * 32 + lane * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        row[e] = cs[e];
+        row[O + e] = cq[e];
+      }
+    }
+  }
 }
 
 // X [N,H,W,64] bf16, Wt [O][576] bf16 -> out [N,H,W,O] bf16 (O = 64 or 128)
 // codes != null: fused ReLU + 2x2 max-pool epilogue; out is then [N,H/2,W/2,O] and codes [N,H/2,W/2,O/8] uint32
 extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, const void* mask_src, void* out,
                             void* codes, void* bits_out, const void* zero_page, int N, int H, int W, int O, int relu,
-                            float mask_scale, int ldx, const void* acc_src, hipStream_t stream) {
+                            float mask_scale, int ldx, const void* acc_src, float* stats_part, int stats_rows,
+                            int* nparts_out, hipStream_t stream) {
   if (N <= 0 || H <= 0 || W <= 0 || (O != 64 && O != 128)) return -10;
   if (ldx < 64 || (ldx & 7)) return -14;
   if (acc_src && codes) return -15;
@@ -532,17 +568,24 @@ extern "C" int dtp_conv_c64(const void* X, const void* Wt, const float* bias, co
     }
   }
   const long grid2 = units * p.RC;
+  p.stats_part = stats_part;
+  if (stats_part) {      // one partial row per workgroup
+    if (codes || mask_src || acc_src || grid2 > stats_rows || !nparts_out) return -16;
+    *nparts_out = (int)grid2;
+  }
   static const int lds_pad = std::getenv("DTP_C64_LDS_PAD") ? std::atoi(std::getenv("DTP_C64_LDS_PAD")) : 0;   // DEBUG: occupancy experiments
   const bool mask = mask_src != nullptr;
   if (O == 64) {
     const int lds = 4 * 6144 + 2 * 4096 + 64 * 4 + lds_pad;
     if (codes) hipLaunchKernelGGL((conv_c64_kernel<64, true, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
     else if (mask) hipLaunchKernelGGL((conv_c64_kernel<64, false, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
+    else if (stats_part) hipLaunchKernelGGL((conv_c64_kernel<64, false, false, true>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
     else hipLaunchKernelGGL((conv_c64_kernel<64, false, false>), dim3((unsigned)grid2), dim3(128), lds, stream, p);
   } else {
     const int lds = 4 * 8192 + 4 * 4096 + 128 * 4 + lds_pad;
     if (codes) hipLaunchKernelGGL((conv_c64_kernel<128, true, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
     else if (mask) hipLaunchKernelGGL((conv_c64_kernel<128, false, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
+    else if (stats_part) hipLaunchKernelGGL((conv_c64_kernel<128, false, false, true>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((conv_c64_kernel<128, false, false>), dim3((unsigned)grid2), dim3(256), lds, stream, p);
   }
   return DTP_CHECK_LAUNCH();

@@ -36,6 +36,8 @@ struct IgemmParams {
   float* partial;         // split-K slabs [z][M][Ncols] f32 (when gridDim.y > 1)
   float* colsum_part;     // optional [tiles_m][Ncols] f32: column sums of the final bf16 output tile
                           // (bias gradient of the layer that consumes this output as its dY)
+  int colsum_sq;          // colsum_part is [tiles_m][2][Ncols]: sums AND sums of squares — the batch
+                          // statistics of a BatchNorm that follows this convolution (bn.hip partial layout)
   const char* zero_page;
   int M, Ncols, C;
   int H, W;
@@ -627,6 +629,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   DTP_STAMP(6)
   {
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + (size_t)m0 * p.ldo * 2, tile_bytes);
     const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
     constexpr int CH = ITER < 4 ? ITER : 4;     // rows per lane and pass: 4 LDS reads in flight, 4 stores back to back
@@ -694,8 +697,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         if (n_ok && pl0 + (c0 + it) * G < rows_valid) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            cs[2 * e] += __uint_as_float(v[it][e] << 16);
-            cs[2 * e + 1] += __uint_as_float(v[it][e] & 0xFFFF0000u);
+            const float lo = __uint_as_float(v[it][e] << 16), hi = __uint_as_float(v[it][e] & 0xFFFF0000u);
+            cs[2 * e] += lo;
+            cs[2 * e + 1] += hi;
+            if (p.colsum_sq) {       // kernel-uniform
+              cq[2 * e] = fmaf(lo, lo, cq[2 * e]);
+              cq[2 * e + 1] = fmaf(hi, hi, cq[2 * e + 1]);
+            }
           }
         }
       }
@@ -716,7 +724,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         float s = 0.f;
 #pragma unroll 4
         for (int k = 0; k < G; ++k) s += red[k * BN + tid];
-        p.colsum_part[(size_t)tm * p.Ncols + n0 + tid] = s;
+        p.colsum_part[(size_t)tm * (p.colsum_sq ? 2 : 1) * p.Ncols + n0 + tid] = s;
+      }
+      if (p.colsum_sq) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[g * BN + q * 8 + e] = cq[e];
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.Ncols) {
+          float s = 0.f;
+#pragma unroll 4
+          for (int k = 0; k < G; ++k) s += red[k * BN + tid];
+          p.colsum_part[((size_t)tm * 2 + 1) * p.Ncols + n0 + tid] = s;
+        }
       }
     }
   }
@@ -772,7 +792,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
-                            const float* dq_a, const float* dq_b, int nsplit, int cfg, hipStream_t stream) {
+                            const float* dq_a, const float* dq_b, int colsum_sq, int nsplit, int cfg,
+                            hipStream_t stream) {
   // fp8 != 0: 8-bit operands, A [M][lda] (fp8 == 1: OCP e4m3, fp8 == 2: e5m2), B [Ncols][ldb] e4m3, bytes; K = C a multiple of 128
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
   if (fp8 && (taps != 1 || (lda & 15) || (ldb & 15))) return -18;
@@ -784,6 +805,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.A = (const char*)A; p.B = (const char*)B; p.bias = bias; p.mask_src = (const char*)mask_src;
   p.out = (char*)out; p.partial = partial; p.zero_page = (const char*)zero_page;
   p.colsum_part = colsum_part;
+  p.colsum_sq = colsum_part ? colsum_sq : 0;
   p.mask_bits = (const unsigned char*)mask_bits; p.bits_out = (unsigned char*)bits_out;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;

@@ -153,6 +153,11 @@ class _ColsumSlot(object):
 
 
 colsum_slot = _ColsumSlot()
+# the same hand-over for BatchNorm's batch statistics: a convolution followed by a training-mode
+# BatchNorm leaves (sum y, sum y^2) per output tile ([tiles][2][C]), bn_fwd_train* takes them when
+# its input is that very tensor and skips its own pass over y
+bn_stats_slot = _ColsumSlot()
+fuse_bn_stats = _os.environ.get("DTP_FUSE_BN_STATS", "1") != "0"      # A/B switch
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
 # conv2_1 dgrad as 2 conv_c64 passes: measured 640 vs 662 TF/s for the implicit GEMM at batch 256 and
@@ -186,7 +191,7 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
            mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
-           bits_out=None, fp8_mode=1):
+           bits_out=None, fp8_mode=1, want_bn_stats=False):
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
@@ -204,6 +209,13 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
         nparts = _cdiv(M, IGEMM_TILES[cfg][0])
         cs_part = workspace.get("colsum_parts", nparts * Ncols, torch.float32, A.device)
         colsum_slot.put(out, cs_part, nparts, Ncols)
+    colsum_sq = 0
+    if (want_bn_stats and fuse_bn_stats and cs_part is None and nsplit == 1 and not out_fp32 and ldo == Ncols
+            and mask_src is None and mask_bits is None):
+        nparts = _cdiv(M, IGEMM_TILES[cfg][0])
+        cs_part = workspace.get("bn_tile_stats", nparts * 2 * Ncols, torch.float32, A.device)
+        bn_stats_slot.put(out, cs_part, nparts, Ncols)
+        colsum_sq = 1
     if nsplit > 1 or out_fp32:          # the 1-bit masks live in the bf16 C-image epilogue only
         if bits_out is not None:
             raise ValueError("igemm: bits_out needs the single-pass bf16 epilogue")
@@ -215,20 +227,26 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  ptr(seed_ptr), int(fp8_mode) if fp8 else 0, ptr(fp8_scales[0]) if fp8 else None,
-                                 ptr(fp8_scales[1]) if fp8 else None, nsplit, cfg, stream())
+                                 ptr(fp8_scales[1]) if fp8 else None, colsum_sq, nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
 
 def _conv_c64(x, w, bias, mask_src, out, N, H, W, O, relu, mask_scale, codes=None, bits_out=None, ldx=64,
-              acc_src=None):
+              acc_src=None, want_bn_stats=False):
     """64 reduction channels: register-resident filters + LDS row ring (csrc/conv_c64.hip).
     ``ldx``: pixel stride of x in elements (x may be a 64-channel slice of a wider tensor);
     ``acc_src``: bf16 partial sums added before the epilogue (may be ``out`` itself)."""
+    part, rows, nparts = None, 0, _ctypes.c_int(0)
+    if want_bn_stats and fuse_bn_stats and codes is None and mask_src is None and acc_src is None:
+        rows = N * _cdiv(W, 32) * max(1, H // 16)          # one partial row per workgroup: the launcher's upper bound
+        part = workspace.get("bn_tile_stats", rows * 2 * O, torch.float32, x.device)
     rc = _lib.hip().dtp_conv_c64(ptr(x), ptr(w), ptr(bias), ptr(mask_src), ptr(out), ptr(codes), ptr(bits_out),
                                  ptr(workspace.zero_page(x.device)), N, H, W, O, int(relu), float(mask_scale),
-                                 int(ldx), ptr(acc_src), stream())
+                                 int(ldx), ptr(acc_src), ptr(part), rows, _ctypes.byref(nparts), stream())
     check(rc, "conv_c64")
+    if part is not None:
+        bn_stats_slot.put(out, part, nparts.value, O)
     return out
 
 
@@ -237,7 +255,7 @@ def relu_bits_for(out):
     return torch.empty(out.numel() // 8, dtype=torch.uint8, device=out.device)
 
 
-def conv3x3_fprop(x, w, bias=None, relu=True, out=None, want_bits=False):
+def conv3x3_fprop(x, w, bias=None, relu=True, out=None, want_bits=False, want_bn_stats=False):
     """y = relu(conv3x3_same(x, w) + bias); x [N,H,W,C] bf16, w [Cout, 9*C] bf16, bias f32 [Cout].
     ``want_bits``: also return (y > 0) packed 1 bit per element — the ReLU-backward mask the data
     gradient of the NEXT convolution applies to its output (16x fewer bytes than re-reading y)."""
@@ -264,10 +282,10 @@ def conv3x3_fprop(x, w, bias=None, relu=True, out=None, want_bits=False):
         if c64 or pick_igemm(M, Cout, ks)[1] == 1:       # split-K passes have no bf16 epilogue to pack from
             bits = relu_bits_for(out)
     if C == 64 and Cout in (64, 128) and "igemm" not in _overrides:
-        _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0, bits_out=bits)
+        _conv_c64(x, w, bias, None, out, N, H, W, Cout, relu, 1.0, bits_out=bits, want_bn_stats=want_bn_stats)
     else:
         _igemm(x, w, bias, None, out, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, relu, 1.0, 0.0, 0,
-               bits_out=bits)
+               bits_out=bits, want_bn_stats=want_bn_stats)
     return (out, bits) if want_bits else out
 
 
@@ -665,8 +683,10 @@ def bn_fwd_train(y, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0
     z = torch.empty_like(y)
     stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
     part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    got = bn_stats_slot.take(y, C) if fuse_bn_stats else None
     check(_lib.hip().dtp_bn_fwd_train(ptr(y), ptr(z), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                      ptr(stats), ptr(part), M, C, float(eps), float(momentum), int(relu), stream()),
+                                      ptr(stats), ptr(part), M, C, float(eps), float(momentum), int(relu),
+                                      ptr(got[0]) if got else None, got[1] if got else 0, stream()),
           "bn_fwd_train")
     return z, stats
 
@@ -734,9 +754,11 @@ def bn_fwd_train_pool(y, gamma, beta, running_mean, running_var, eps=1e-5, momen
     codes = torch.empty((N, H // 2, W // 2, C // 8), dtype=torch.int32, device=y.device)
     stats = torch.empty(4 * C, dtype=torch.float32, device=y.device)
     part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
+    got = bn_stats_slot.take(y, C) if fuse_bn_stats else None
     check(_lib.hip().dtp_bn_fwd_train_pool(ptr(y), ptr(zp), ptr(codes), ptr(gamma), ptr(beta), ptr(running_mean),
                                            ptr(running_var), ptr(stats), ptr(part), N, H, W, C, float(eps),
-                                           float(momentum), stream()), "bn_fwd_train_pool")
+                                           float(momentum), ptr(got[0]) if got else None, got[1] if got else 0,
+                                           stream()), "bn_fwd_train_pool")
     return zp, codes, stats
 
 

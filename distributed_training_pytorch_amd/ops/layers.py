@@ -137,8 +137,10 @@ class _Conv3x3Fn(torch.autograd.Function):
         # 1-bit ReLU masks: this layer packs (y > 0) for the data gradient of the NEXT convolution and
         # picks up the bits its producer left on x (tensor attribute set in Conv3x3.forward)
         want_bits = K.relu_bitmask and layer.relu and layer.emit_relu_bits
+        # a training-mode BatchNorm follows: the epilogue leaves its batch statistics behind
+        want_stats = bool(getattr(layer, "bn_follows", False)) and layer.training and not layer.relu
         y = K.conv3x3_fprop(x, arena.lp(weight), bias.detach() if bias is not None else None, relu=layer.relu,
-                            want_bits=want_bits)
+                            want_bits=want_bits, want_bn_stats=want_stats)
         if want_bits:
             y, layer._bits_tmp = y
         ctx.layer = layer

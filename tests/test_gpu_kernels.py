@@ -920,3 +920,67 @@ def test_stream_delay_holds_the_stream_for_about_the_requested_time():
     with pytest.raises(Exception):
         k.stream_delay(5000.0)              # a head start, not a timer
     assert k.wgrad_is_persistent(64, 64) and k.wgrad_is_persistent(64, 128) and not k.wgrad_is_persistent(128, 128)
+
+
+@pytest.mark.parametrize("shape", [(2, 28, 28, 128, 256), (3, 14, 14, 256, 512), (2, 56, 56, 128, 128),
+                                   (2, 28, 28, 64, 128), (3, 20, 36, 64, 64), (1, 48, 70, 64, 64)])
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("cfg", [3, 16, 17])
+def test_batchnorm_statistics_from_the_convolution_epilogue(shape, pool, cfg):
+    """The implicit GEMM in front of a training-mode BatchNorm leaves (sum y, sum y^2) per output
+    tile; bn_fwd_train / bn_fwd_train_pool take them instead of reading y again.  Same statistics
+    as the stand-alone reduction up to f32 summation order, same normalised output up to a bf16
+    rounding at a boundary, and the hand-over only happens for the very tensor the conv wrote."""
+    k = _k()
+    N, H, W, C, Co = shape
+    if C == 64 and cfg != 3:
+        pytest.skip("64 reduction channels take conv_c64 (its store epilogue leaves the statistics): one case")
+    torch.manual_seed(77)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda") * 0.5
+    gamma = torch.rand(Co, device="cuda") + 0.5
+    beta = torch.randn(Co, device="cuda") * 0.1
+
+    def run(fused):
+        k.fuse_bn_stats = fused
+        if C != 64:
+            k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)     # tiny test grids would take split-K (no bf16 epilogue)
+        try:
+            y = k.conv3x3_fprop(x, w, b, relu=False, want_bn_stats=True)
+        finally:
+            k._overrides.pop("igemm", None)
+        handed = k.bn_stats_slot.tensor is not None
+        rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+        if pool:
+            z, codes, stats = k.bn_fwd_train_pool(y, gamma, beta, rm, rv)
+        else:
+            z, stats = k.bn_fwd_train(y, gamma, beta, rm, rv)
+            codes = None
+        assert k.bn_stats_slot.tensor is None          # consumed (or never there)
+        return y, z, codes, stats, rm, rv, handed
+    try:
+        y0, z0, c0, s0, rm0, rv0, h0 = run(False)
+        y1, z1, c1, s1, rm1, rv1, h1 = run(True)
+    finally:
+        k.fuse_bn_stats = True
+    assert not h0 and h1
+    assert torch.equal(y0, y1)
+    yf = y0.float().view(-1, Co)
+    assert torch.allclose(s1[:Co], yf.mean(0), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(s1[Co:2 * Co], (yf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-6)
+    assert torch.allclose(rm0, rm1, rtol=2e-5, atol=2e-6) and torch.allclose(rv0, rv1, rtol=2e-5, atol=2e-6)
+    d = (z0.float() - z1.float()).abs()
+    assert (d > 0).float().mean().item() < 1e-3 and (d <= 0.0079 * z0.float().abs() + 1e-6).all()
+    # a different tensor of the same shape must not pick the statistics up
+    if C != 64:
+        k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)
+    try:
+        y2 = k.conv3x3_fprop(x, w, b, relu=False, want_bn_stats=True)
+    finally:
+        k._overrides.pop("igemm", None)
+    other = y2.clone()
+    rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
+    _, s2 = k.bn_fwd_train(other, gamma, beta, rm, rv)
+    assert k.bn_stats_slot.tensor is None and torch.equal(s2, s0)
