@@ -46,7 +46,7 @@ _SIGS = {
     "dtp_nchw_to_nhwc_bf16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                               c_void_p, c_void_p, c_void_p],
     "dtp_conv1_fprop": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
-                        c_void_p, c_void_p, c_void_p],
+                        c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dtp_conv1_wgrad": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                         c_int, c_float, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p],
     "dtp_cast_f32_bf16": [c_void_p, c_void_p, c_size_t, c_void_p],

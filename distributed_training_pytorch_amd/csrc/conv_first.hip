@@ -36,6 +36,8 @@ struct Conv1Params {
   long M;                 // N*H*W          (< 2^31, and the batch < 4 GiB: the launchers chunk)
   unsigned hw;            // H*W
   float rcp_hw, rcp_w;    // 1/(H*W), 1/W for the float-estimate divisions
+  float* stats_part;      // STATS kernels: [gridDim.x][2][64] f32 (sum y, sum y^2) of the stored outputs — batch
+                          // statistics of a BatchNorm that follows (bn.hip partial layout)
 };
 
 template <typename T> DTP_DEVINL float ld_f32(const T* p);
@@ -134,7 +136,7 @@ DTP_DEVINL void gather_patch(const Conv1Params& p, const Conv1Norm& nm, long pix
 // stores.  The one-shot form (one tile per workgroup, 3 workgroups per CU by LDS) was a serial
 // load-latency chain per workgroup: 3.3 TB/s of output at batch 1024.  The gather is issued BEFORE
 // the tile's stores so that waiting for it (vmcnt counts in issue order) never drains the stores.
-template <typename T>
+template <typename T, bool STATS = false>
 __global__ __launch_bounds__(256) void conv1_fprop_kernel(const Conv1Params p, const int ntiles) {
   // LDS: A image [256][32] bf16 (64-B rows, 16 KiB) | W image [64][32] (4 KiB) | C image [256][64] (32 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,6 +174,8 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const Conv1Params p, c
     bvv[j] = p.bias ? *(const f32x4_t*)(p.bias + j * 16 + cq) : (f32x4_t){0.f, 0.f, 0.f, 0.f};
   typedef short s16x2_t __attribute__((ext_vector_type(2)));
   const bool relu = p.relu != 0;
+  // STATS: a thread stores the same 8-channel chunk (tid & 7) of 8 pixels per tile
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     {  // im2col row of this thread's pixel (loads issued one tile ago)
@@ -222,6 +226,31 @@ __global__ __launch_bounds__(256) void conv1_fprop_kernel(const Conv1Params p, c
       if (m0 + pl >= p.M) continue;
       const u32x4_t v = *(const u32x4_t*)(lC + pl * 128 + ((q ^ (pl & 7)) << 4));
       *(u32x4_t*)(p.y + (m0 + pl) * 64 + q * 8) = v;
+      if constexpr (STATS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xFFFF0000u);
+          cs[2 * e] += lo;
+          cs[2 * e + 1] += hi;
+          sq[2 * e] = fmaf(lo, lo, sq[2 * e]);
+          sq[2 * e + 1] = fmaf(hi, hi, sq[2 * e + 1]);
+        }
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // 32 threads (tid >> 3) share a chunk: fold them through LDS in a fixed order (the C image is dead)
+    float* red = (float*)lC;                  // [32][64]
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(tid >> 3) * 64 + (tid & 7) * 8 + e] = which ? sq[e] : cs[e];
+      __syncthreads();
+      if (tid < 64) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += red[k * 64 + tid];
+        p.stats_part[((size_t)blockIdx.x * 2 + which) * 64 + tid] = t;
+      }
     }
   }
 }
@@ -473,8 +502,10 @@ static int conv1_esz(int in_kind) { return in_kind == 0 ? 4 : (in_kind == 1 ? 2 
 
 extern "C" int dtp_conv1_fprop(const void* x, int in_kind, const void* w, const float* bias, void* y, int N, int Cin,
                                int H, int W, int relu, float scale, const float* mean, const float* inv_std,
-                               hipStream_t s) {
+                               float* stats_part, int stats_rows, int* nparts_out, hipStream_t s) {
   if (in_kind < 0 || in_kind > 2) return -11;
+  if (stats_part && !nparts_out) return -14;
+  int rows_used = 0;
   if (N <= 0 || Cin != 3 || H <= 0 || W <= 0 || H >= 0x7ff0 || W >= 0x7ff0) return -10;
   const int esz = conv1_esz(in_kind), nmax = conv1_max_batch(H, W, esz);
   if (nmax < 1) return -13;
@@ -489,10 +520,21 @@ extern "C" int dtp_conv1_fprop(const void* x, int in_kind, const void* w, const 
     c.w = (const bf16_t*)w; c.bias = bias; c.y = (bf16_t*)y + (size_t)n0 * H * W * 64; c.relu = relu;
     const int tiles = (int)((c.M + C1_TILE - 1) / C1_TILE);
     const int grid = tiles < cap ? tiles : cap;
+    c.stats_part = nullptr;
+    if (stats_part) {            // one partial row per workgroup, chunk after chunk
+      if (rows_used + grid > stats_rows) return -15;
+      c.stats_part = stats_part + (size_t)rows_used * 128;
+      rows_used += grid;
+      if (in_kind == 0) hipLaunchKernelGGL((conv1_fprop_kernel<float, true>), dim3(grid), dim3(256), lds, s, c, tiles);
+      else if (in_kind == 1) hipLaunchKernelGGL((conv1_fprop_kernel<bf16_t, true>), dim3(grid), dim3(256), lds, s, c, tiles);
+      else hipLaunchKernelGGL((conv1_fprop_kernel<uint8_t, true>), dim3(grid), dim3(256), lds, s, c, tiles);
+      continue;
+    }
     if (in_kind == 0) hipLaunchKernelGGL(conv1_fprop_kernel<float>, dim3(grid), dim3(256), lds, s, c, tiles);
     else if (in_kind == 1) hipLaunchKernelGGL(conv1_fprop_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, c, tiles);
     else hipLaunchKernelGGL(conv1_fprop_kernel<uint8_t>, dim3(grid), dim3(256), lds, s, c, tiles);
   }
+  if (stats_part) *nparts_out = rows_used;
   return DTP_CHECK_LAUNCH();
 }
 

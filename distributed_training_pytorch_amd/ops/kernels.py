@@ -616,7 +616,7 @@ def nchw_to_nhwc_bf16(x, c_pad, scale=1.0, mean=None, inv_std=None):
 _IN_KINDS = {torch.float32: 0, BF16: 1, torch.uint8: 2}
 
 
-def conv1_fprop(x, w, bias, relu=True, scale=1.0, mean=None, inv_std=None):
+def conv1_fprop(x, w, bias, relu=True, scale=1.0, mean=None, inv_std=None, want_bn_stats=False):
     """First layer: NCHW f32/bf16/u8 [N,3,H,W] -> NHWC bf16 [N,H,W,64] = relu(conv3x3(norm(x)) + b)."""
     if x.dtype not in _IN_KINDS or not x.is_cuda or not x.is_contiguous() or x.dim() != 4 or x.shape[1] != 3:
         raise ValueError("conv1_fprop: need contiguous CUDA NCHW f32/bf16/u8 with 3 channels")
@@ -627,9 +627,18 @@ def conv1_fprop(x, w, bias, relu=True, scale=1.0, mean=None, inv_std=None):
         _need(bias, torch.float32, "bias")
     N, Cin, H, W = x.shape
     y = torch.empty((N, H, W, 64), dtype=BF16, device=x.device)
+    part, rows, nparts = None, 0, _ctypes.c_int(0)
+    if want_bn_stats and fuse_bn_stats:
+        rows = 1024                                    # persistent grid: <= 768 workgroups per launch
+        part = workspace.get("bn_tile_stats", rows * 2 * 64, torch.float32, x.device)
     rc = _lib.hip().dtp_conv1_fprop(ptr(x), _IN_KINDS[x.dtype], ptr(w), ptr(bias), ptr(y), N, Cin, H, W, int(relu),
-                                    float(scale), ptr(mean), ptr(inv_std), stream())
+                                    float(scale), ptr(mean), ptr(inv_std), ptr(part), rows, _ctypes.byref(nparts),
+                                    stream())
+    if rc == -15 and part is not None:                 # more batch chunks than partial rows: no hand-over
+        return conv1_fprop(x, w, bias, relu, scale, mean, inv_std)
     check(rc, "conv1_fprop")
+    if part is not None:
+        bn_stats_slot.put(y, part, nparts.value, 64)
     return y
 
 

@@ -305,8 +305,9 @@ class _ConvFirstFn(torch.autograd.Function):
         ctx.layer = layer
         ctx.fast = x.shape[1] == 3
         if ctx.fast:
+            want_stats = bool(getattr(layer, "bn_follows", False)) and layer.training and not layer.relu
             y = K.conv1_fprop(x, arena.lp(weight), bias.detach(), layer.relu, layer.in_scale, layer.in_mean,
-                              layer.in_inv_std)
+                              layer.in_inv_std, want_bn_stats=want_stats)
             ctx.save_for_backward(x, y, weight, bias)
             return y
         xp = K.nchw_to_nhwc_bf16(x, layer.c_pad, layer.in_scale, layer.in_mean, layer.in_inv_std)

@@ -984,3 +984,43 @@ def test_batchnorm_statistics_from_the_convolution_epilogue(shape, pool, cfg):
     rm, rv = torch.zeros(Co, device="cuda"), torch.ones(Co, device="cuda")
     _, s2 = k.bn_fwd_train(other, gamma, beta, rm, rv)
     assert k.bn_stats_slot.tensor is None and torch.equal(s2, s0)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 3, 40, 36), torch.float32), ((2, 3, 64, 64), torch.uint8),
+                                         ((5, 3, 30, 50), torch.bfloat16)])
+def test_batchnorm_statistics_from_the_first_convolution(shape, dtype):
+    """conv1_fprop's store loop leaves the batch statistics of a following BatchNorm (one partial
+    row per persistent workgroup); bn_fwd_train takes them instead of reading y again."""
+    k = _k()
+    torch.manual_seed(78)
+    if dtype == torch.uint8:
+        x = torch.randint(0, 256, shape, device="cuda", dtype=torch.uint8)
+        scale = 1.0 / 255.0
+    else:
+        x = torch.randn(shape, device="cuda").to(dtype)
+        scale = 1.0
+    w = _rand(64, 27, scale=(2.0 / 27) ** 0.5)
+    b = torch.randn(64, device="cuda") * 0.3
+    gamma = torch.rand(64, device="cuda") + 0.5
+    beta = torch.randn(64, device="cuda") * 0.1
+    res = []
+    try:
+        for fused in (False, True):
+            k.fuse_bn_stats = fused
+            y = k.conv1_fprop(x, w, b, relu=False, scale=scale, want_bn_stats=True)
+            assert (k.bn_stats_slot.tensor is not None) == fused
+            rm, rv = torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+            z, stats = k.bn_fwd_train(y, gamma, beta, rm, rv)
+            assert k.bn_stats_slot.tensor is None
+            res.append((y, z, stats, rm, rv))
+    finally:
+        k.fuse_bn_stats = True
+    (y0, z0, s0, rm0, rv0), (y1, z1, s1, rm1, rv1) = res
+    assert torch.equal(y0, y1)
+    yf = y0.float().view(-1, 64)
+    assert torch.allclose(s1[:64], yf.mean(0), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(s1[64:128], (yf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+    assert torch.allclose(s0, s1, rtol=2e-5, atol=2e-6)
+    assert torch.allclose(rm0, rm1, rtol=2e-5, atol=2e-6) and torch.allclose(rv0, rv1, rtol=2e-5, atol=2e-6)
+    d = (z0.float() - z1.float()).abs()
+    assert (d > 0).float().mean().item() < 1e-3 and (d <= 0.0079 * z0.float().abs() + 1e-6).all()
