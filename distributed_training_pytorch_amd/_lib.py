@@ -26,7 +26,8 @@ c_void_p, c_int, c_float, c_size_t, c_long, c_ull = (ctypes.c_void_p, ctypes.c_i
 _SIGS = {
     "dtp_igemm_nt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                     c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+                     c_float, c_float, c_ull, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                     c_int, c_int, c_void_p],
     "dtp_wgrad_tt": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_int, c_float, c_int, c_int, c_void_p],
@@ -59,7 +60,7 @@ _SIGS = {
     "dtp_bn_fwd_eval": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float,
                         c_int, c_void_p],
     "dtp_bn_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_float,
-                   c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+                   c_void_p, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p],
     "dtp_bn_fwd_train_pool": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p],
     "dtp_bn_bwd_pool": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,

@@ -408,6 +408,33 @@ __global__ __launch_bounds__(256) void bn_fold_tiles_kernel(const float* __restr
   }
 }
 
+// The backward form: the data gradient that produced dz left (sum dyh, sum dyh*y) per tile (igemm.hip
+// bn_y); sum dyh*xhat = rstd * (sum dyh*y - mean * sum dyh), applied per folded row.
+__global__ __launch_bounds__(256) void bn_fold_tiles_bwd_kernel(const float* __restrict__ tp, int ntiles, int per, int C,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, float* __restrict__ partial) {
+  const int r0 = blockIdx.x * per;
+  int r1 = r0 + per;
+  if (r1 > ntiles) r1 = ntiles;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      a += tp[(size_t)r * 2 * C + c];
+      b += tp[((size_t)r * 2 + 1) * C + c];
+    }
+    partial[(size_t)blockIdx.x * 2 * C + c] = a;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = rstd[c] * (b - mean[c] * a);
+  }
+}
+
+int bn_fold_tiles_bwd(const float* tp, int ntiles, int C, const float* mean, const float* rstd, float* partial,
+                      hipStream_t s) {
+  const int per = (ntiles + BN_MAXBLK - 1) / BN_MAXBLK;
+  const int nblk = (ntiles + per - 1) / per;
+  hipLaunchKernelGGL(bn_fold_tiles_bwd_kernel, dim3(nblk), dim3(256), 0, s, tp, ntiles, per, C, mean, rstd, partial);
+  return nblk;
+}
+
 // -> number of partial rows written
 int bn_fold_tiles(const float* tp, int ntiles, int C, float* partial, hipStream_t s) {
   const int per = (ntiles + BN_MAXBLK - 1) / BN_MAXBLK;
@@ -464,12 +491,16 @@ extern "C" int dtp_bn_fwd_eval(const void* y, void* z, const float* gamma, const
 // stats as written by dtp_bn_fwd_train; work: 2 x C floats (c1 | c2)
 extern "C" int dtp_bn_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* stats, void* dgamma,
                           void* dbeta, int grads_fp32, float beta_g, float beta_b, float* partial, float* work, long M,
-                          int C, int relu, hipStream_t s) {
+                          int C, int relu, const float* tile_partial, int ntiles, hipStream_t s) {
   if (!bn_shape_ok(M, C)) return -10;
-  const int nblk = bn_grid(M, C);
+  if (tile_partial && ntiles < 1) return -11;
+  int nblk = bn_grid(M, C);
   const float *mean = stats, *rstd = stats + C, *scale = stats + 2 * C, *shift = stats + 3 * C;
-  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, (const u32x4_t*)dz, scale,
-                     shift, mean, rstd, partial, M, C, relu);
+  if (tile_partial)      // the producer of dz left the two reductions per tile
+    nblk = bn_fold_tiles_bwd(tile_partial, ntiles, C, mean, rstd, partial, s);
+  else
+    hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3(nblk), dim3(BN_T), 0, s, (const u32x4_t*)y, (const u32x4_t*)dz, scale,
+                       shift, mean, rstd, partial, M, C, relu);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, s, partial, nblk, C, M, dgamma, dbeta,
                      grads_fp32, beta_g, beta_b, work, work + C);
   const long nvec = M * (C >> 3);

@@ -36,6 +36,10 @@ struct IgemmParams {
   float* partial;         // split-K slabs [z][M][Ncols] f32 (when gridDim.y > 1)
   float* colsum_part;     // optional [tiles_m][Ncols] f32: column sums of the final bf16 output tile
                           // (bias gradient of the layer that consumes this output as its dY)
+  const char* bn_y;       // optional bf16 [M][ldo] (with colsum_sq): this output is dz, the gradient of
+  const float* bn_scale;  //   z = relu(y*scale + shift) (a training-mode BatchNorm + ReLU); the partial rows become
+  const float* bn_shift;  //   (sum dyh, sum dyh*y) with dyh = dz * (y*scale + shift > 0)   [no mask when bn_scale is null]
+                          //   — the two reductions of the BatchNorm backward, which then skips its pass over (dz, y)
   int colsum_sq;          // colsum_part is [tiles_m][2][Ncols]: sums AND sums of squares — the batch
                           // statistics of a BatchNorm that follows this convolution (bn.hip partial layout)
   const char* zero_page;
@@ -630,6 +634,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   {
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bsc[8], bsh[8];                     // bn_y mode: scale / shift of this lane's 8 channels
+    if (p.bn_y && p.bn_scale) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bsc[e] = n_ok ? p.bn_scale[n + e] : 0.f;
+        bsh[e] = n_ok ? p.bn_shift[n + e] : 0.f;
+      }
+    }
     const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + (size_t)m0 * p.ldo * 2, tile_bytes);
     const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
     constexpr int CH = ITER < 4 ? ITER : 4;     // rows per lane and pass: 4 LDS reads in flight, 4 stores back to back
@@ -691,7 +703,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, bo_rs, (int)(n_ok ? voff >> 4 : DTP_OOB_OFF), (c0 + it) * (row_step >> 4), 0);
       }
     }
-    if (p.colsum_part) {
+    if (p.colsum_part && p.bn_y) {       // kernel-uniform: BatchNorm-backward reductions of this dz tile
+      const __amdgpu_buffer_rsrc_t by_rs = make_rsrc(p.bn_y + (size_t)m0 * p.ldo * 2, tile_bytes);
+      u32x4_t yv[CH];
+#pragma unroll
+      for (int it = 0; it < CH; ++it)
+        yv[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(by_rs, (int)voff, (c0 + it) * row_step, 0));
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        if (n_ok && pl0 + (c0 + it) * G < rows_valid) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ylo = __uint_as_float(yv[it][e] << 16), yhi = __uint_as_float(yv[it][e] & 0xFFFF0000u);
+            float dlo = __uint_as_float(v[it][e] << 16), dhi = __uint_as_float(v[it][e] & 0xFFFF0000u);
+            if (p.bn_scale) {
+              dlo = fmaf(ylo, bsc[2 * e], bsh[2 * e]) > 0.f ? dlo : 0.f;
+              dhi = fmaf(yhi, bsc[2 * e + 1], bsh[2 * e + 1]) > 0.f ? dhi : 0.f;
+            }
+            cs[2 * e] += dlo;
+            cs[2 * e + 1] += dhi;
+            cq[2 * e] = fmaf(dlo, ylo, cq[2 * e]);
+            cq[2 * e + 1] = fmaf(dhi, yhi, cq[2 * e + 1]);
+          }
+        }
+      }
+    } else if (p.colsum_part) {
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
         if (n_ok && pl0 + (c0 + it) * G < rows_valid) {
@@ -792,8 +828,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             int taps, int H,
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
-                            const float* dq_a, const float* dq_b, int colsum_sq, int nsplit, int cfg,
-                            hipStream_t stream) {
+                            const float* dq_a, const float* dq_b, int colsum_sq, const void* bn_y,
+                            const float* bn_scale, const float* bn_shift, int nsplit, int cfg, hipStream_t stream) {
   // fp8 != 0: 8-bit operands, A [M][lda] (fp8 == 1: OCP e4m3, fp8 == 2: e5m2), B [Ncols][ldb] e4m3, bytes; K = C a multiple of 128
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
   if (fp8 && (taps != 1 || (lda & 15) || (ldb & 15))) return -18;
@@ -806,6 +842,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.out = (char*)out; p.partial = partial; p.zero_page = (const char*)zero_page;
   p.colsum_part = colsum_part;
   p.colsum_sq = colsum_part ? colsum_sq : 0;
+  p.bn_y = (const char*)bn_y; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  if (bn_y && (!colsum_part || !colsum_sq || out_fp32 || (bn_scale && !bn_shift))) return -21;
   p.mask_bits = (const unsigned char*)mask_bits; p.bits_out = (unsigned char*)bits_out;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
   p.out_fp32 = out_fp32; p.relu = relu; p.mask_scale = mask_scale; p.drop_p = drop_p; p.seed = seed;

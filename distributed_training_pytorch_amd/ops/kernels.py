@@ -157,6 +157,9 @@ colsum_slot = _ColsumSlot()
 # BatchNorm leaves (sum y, sum y^2) per output tile ([tiles][2][C]), bn_fwd_train* takes them when
 # its input is that very tensor and skips its own pass over y
 bn_stats_slot = _ColsumSlot()
+# ... and for its backward: the data gradient that produces dz (the gradient of relu(bn(y))) leaves
+# (sum dyh, sum dyh*y) per tile when it is told y / scale / shift of that BatchNorm; bn_bwd takes them
+bn_bwd_slot = _ColsumSlot()
 fuse_bn_stats = _os.environ.get("DTP_FUSE_BN_STATS", "1") != "0"      # A/B switch
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
@@ -191,7 +194,7 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
            mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
-           bits_out=None, fp8_mode=1, want_bn_stats=False):
+           bits_out=None, fp8_mode=1, want_bn_stats=False, bn_bwd_src=None):
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
@@ -216,6 +219,18 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
         cs_part = workspace.get("bn_tile_stats", nparts * 2 * Ncols, torch.float32, A.device)
         bn_stats_slot.put(out, cs_part, nparts, Ncols)
         colsum_sq = 1
+    bn_y = bn_sc = bn_sh = None
+    if (bn_bwd_src is not None and fuse_bn_stats and cs_part is None and nsplit == 1 and not out_fp32
+            and ldo == Ncols and mask_src is None and mask_bits is None and not relu and bias is None):
+        y_src, stats, bn_relu = bn_bwd_src          # stats = [mean | rstd | scale | shift]
+        if y_src.numel() == M * Ncols and y_src.dtype == BF16 and y_src.is_contiguous() and stats.numel() == 4 * Ncols:
+            nparts = _cdiv(M, IGEMM_TILES[cfg][0])
+            cs_part = workspace.get("bn_tile_stats_bwd", nparts * 2 * Ncols, torch.float32, A.device)
+            bn_bwd_slot.put(out, cs_part, nparts, Ncols)
+            colsum_sq = 1
+            bn_y = y_src
+            if bn_relu:
+                bn_sc, bn_sh = stats[2 * Ncols:3 * Ncols], stats[3 * Ncols:]
     if nsplit > 1 or out_fp32:          # the 1-bit masks live in the bf16 C-image epilogue only
         if bits_out is not None:
             raise ValueError("igemm: bits_out needs the single-pass bf16 epilogue")
@@ -227,7 +242,8 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
                                  ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo,
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  ptr(seed_ptr), int(fp8_mode) if fp8 else 0, ptr(fp8_scales[0]) if fp8 else None,
-                                 ptr(fp8_scales[1]) if fp8 else None, colsum_sq, nsplit, cfg, stream())
+                                 ptr(fp8_scales[1]) if fp8 else None, colsum_sq, ptr(bn_y), ptr(bn_sc), ptr(bn_sh),
+                                 nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
@@ -319,10 +335,13 @@ def split_dgrad_weight(wd, Cin, Co):
     return (w3[:, :, :64].contiguous().view(Cin, 9 * 64), w3[:, :, 64:128].contiguous().view(Cin, 9 * 64))
 
 
-def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None, wd_halves=None):
+def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None, wd_halves=None, bn_bwd_src=None):
     """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout].
     ``mask_bits`` (from ``conv3x3_fprop(..., want_bits=True)`` of the layer that produced
-    ``mask_src``) replaces the 2-byte-per-element mask read by 1 bit per element."""
+    ``mask_src``) replaces the 2-byte-per-element mask read by 1 bit per element.
+    ``bn_bwd_src`` = (y, stats, relu) of the training-mode BatchNorm(+ReLU) whose OUTPUT this
+    convolution consumed: dx is that BatchNorm's dz, and the kernel leaves the two reductions of
+    its backward pass behind (``bn_bwd_slot``)."""
     _need(dy, BF16, "dy")
     _need(wd, BF16, "wd")
     N, H, W, Co = dy.shape
@@ -352,7 +371,8 @@ def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=Non
         return _conv_c64(dy2[:, 64:], hi, None, mask_src, out, N, H, W, Cin, False, mask_scale, ldx=Co, acc_src=out)
     # a masked data-gradient is the dY of the convolution below: leave its column sums behind
     return _igemm(dy, wd, None, mask_src, out, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
-                  mask_scale, 0.0, 0, want_colsum=mask_src is not None, mask_bits=mask_bits)
+                  mask_scale, 0.0, 0, want_colsum=mask_src is not None, mask_bits=mask_bits,
+                  bn_bwd_src=bn_bwd_src if mask_src is None else None)
 
 
 def linear_fwd(x, w, bias=None, relu=False, drop_p=0.0, seed=0, out_fp32=False, out=None, seed_ptr=None):
@@ -737,9 +757,11 @@ def bn_bwd(y, dz, gamma, stats, dgamma, dbeta, beta_g=0.0, beta_b=0.0, relu=True
     dy = torch.empty_like(y)
     part = workspace.get("bn_partial", 1024 * 2 * 512, torch.float32, y.device)
     work = workspace.get("bn_work", 2 * 512, torch.float32, y.device)
+    got = bn_bwd_slot.take(dz, C) if fuse_bn_stats else None
     check(_lib.hip().dtp_bn_bwd(ptr(y), ptr(dz), ptr(dy), ptr(gamma), ptr(stats), ptr(dgamma), ptr(dbeta),
                                 int(dgamma.dtype == torch.float32), float(beta_g), float(beta_b), ptr(part), ptr(work),
-                                y.numel() // C, C, int(relu), stream()), "bn_bwd")
+                                y.numel() // C, C, int(relu), ptr(got[0]) if got else None, got[1] if got else 0,
+                                stream()), "bn_bwd")
     return dy
 
 

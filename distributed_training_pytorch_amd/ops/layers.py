@@ -146,6 +146,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         ctx.layer = layer
         ctx.has_bias = bias is not None
         ctx.mask_bits = getattr(x, "_dtp_relu_bits", None) if (K.relu_bitmask and layer.input_is_relu_out) else None
+        # x is the output of a training-mode BatchNorm(+ReLU): (its input y, its statistics, relu) — this
+        # layer's data gradient then leaves that BatchNorm's backward reductions behind
+        ctx.bn_src = getattr(x, "_dtp_bn_src", None)
         ctx.save_for_backward(x, y, weight, bias)
         return y
 
@@ -178,7 +181,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
-                                 wd_halves=layer._wd_halves(wd))
+                                 wd_halves=layer._wd_halves(wd), bn_bwd_src=ctx.bn_src)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)    # join before the reducer ships the gradient
         if ctx.has_bias:
@@ -592,6 +595,7 @@ class _BatchNormReLUFn(torch.autograd.Function):
                                   layer.running_mean, layer.running_var, layer.eps, layer.momentum, layer.relu)
         ctx.layer = layer
         ctx.save_for_backward(y, stats, weight, bias)
+        layer._bn_src_tmp = (y, stats, bool(layer.relu))     # travels with z to the consuming convolution
         return z
 
     @staticmethod
@@ -681,7 +685,11 @@ class BatchNormReLU(FusedLayer):
             return F.relu(y) if self.relu else y
         if self.training:
             self.num_batches_tracked += 1
-            return _BatchNormReLUFn.apply(x, self.weight, self.bias, self)
+            z = _BatchNormReLUFn.apply(x, self.weight, self.bias, self)
+            src = self.__dict__.pop("_bn_src_tmp", None)
+            if src is not None:
+                z._dtp_bn_src = src
+            return z
         arena = _arena_of(self)
         if torch.is_grad_enabled() and x.requires_grad:
             raise RuntimeError("eval-mode BatchNormReLU on the GPU is inference-only (no autograd)")

@@ -1024,3 +1024,52 @@ def test_batchnorm_statistics_from_the_first_convolution(shape, dtype):
     assert torch.allclose(rm0, rm1, rtol=2e-5, atol=2e-6) and torch.allclose(rv0, rv1, rtol=2e-5, atol=2e-6)
     d = (z0.float() - z1.float()).abs()
     assert (d > 0).float().mean().item() < 1e-3 and (d <= 0.0079 * z0.float().abs() + 1e-6).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 28, 28, 128, 256), (3, 14, 14, 256, 512), (2, 56, 56, 128, 128)])
+@pytest.mark.parametrize("cfg", [3, 16, 17])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_backward_reductions_from_the_data_gradient_epilogue(shape, cfg, relu):
+    """The data gradient that produces dz of a BatchNorm(+ReLU) leaves (sum dyh, sum dyh*y) per tile
+    when it is given that BatchNorm's y / scale / shift; bn_bwd takes them instead of reading (dz, y)
+    once more.  Same dgamma / dbeta / dy as the stand-alone reduction up to f32 summation order."""
+    k = _k()
+    N, H, W, C, Co = shape          # the BatchNorm has C channels; the convolution above maps C -> Co
+    torch.manual_seed(79)
+    y = (_rand(N, H, W, C).float() * 1.5 + 0.3).to(BF16)
+    gamma = torch.rand(C, device="cuda") + 0.5
+    beta = torch.randn(C, device="cuda") * 0.2
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    z, stats = k.bn_fwd_train(y, gamma, beta, rm, rv, relu=relu)
+    dyn = _rand(N, H, W, Co, scale=0.1)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    wd = k.conv_weight_to_dgrad(w, Co, C)
+    res = []
+    try:
+        for fused in (False, True):
+            k.fuse_bn_stats = fused
+            k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)
+            try:
+                dz = k.conv3x3_dgrad(dyn, wd, bn_bwd_src=(y, stats, relu))
+            finally:
+                k._overrides.pop("igemm", None)
+            assert (k.bn_bwd_slot.tensor is not None) == fused
+            dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            dy = k.bn_bwd(y, dz, gamma, stats, dg, db, relu=relu)
+            assert k.bn_bwd_slot.tensor is None
+            res.append((dz, dy, dg, db))
+    finally:
+        k.fuse_bn_stats = True
+    (dz0, dy0, dg0, db0), (dz1, dy1, dg1, db1) = res
+    assert torch.equal(dz0, dz1)
+    # f32 reference of the two reductions
+    yf, dzf = y.float().view(-1, C), dz0.float().view(-1, C)
+    mean, rstd, sc, sh = stats[:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
+    dyh = dzf * ((yf * sc + sh) > 0) if relu else dzf
+    ref_db = dyh.sum(0)
+    ref_dg = (dyh * (yf - mean) * rstd).sum(0)
+    tol_b = 1e-3 * dyh.abs().sum(0).max().item()
+    assert (db1 - ref_db).abs().max().item() < tol_b and (dg1 - ref_dg).abs().max().item() < 2 * tol_b
+    assert (db1 - db0).abs().max().item() < 1e-4 * dyh.abs().sum(0).max().item()
+    assert (dg1 - dg0).abs().max().item() < 2e-4 * dyh.abs().sum(0).max().item()
+    _close(dy1, dy0.float(), 1e-2, 1e-2 * dy0.float().abs().max().item(), "bn_bwd dy from epilogue reductions")
