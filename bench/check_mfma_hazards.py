@@ -9,6 +9,8 @@ assembly along fall-through AND branch targets and reports every such place.
 
   python bench/check_mfma_hazards.py [file.hip ...]      (default: every csrc/*.hip; exit 1 on a finding)
 
+It also fails on any kernel that needs scratch memory (``.amdhsa_private_segment_fixed_size`` > 0).
+
 Wait states are counted the way LLVM's hazard recognizer does (one per instruction, ``s_nop N`` =
 N + 1), so an intervening independent MFMA counts 1 although it occupies the pipe for its passes —
 conservative.  Needed: passes + 3, with the pass counts of gfx950's double-K forms as measured
@@ -134,7 +136,17 @@ def main():
             for name, (ins, labels) in parse(out).items():
                 n_mfma += sum(1 for mn, _ in ins if mn.startswith("v_mfma"))
                 found += check_kernel(name, ins, labels)
-            print("%-22s %5d MFMAs, %d finding(s)" % (os.path.basename(f), n_mfma, len(found)))
+            # second check on the same assembly: no kernel of the tree may need scratch memory (a register
+            # spill in an epilogue lambda once cost a 256x256 tile more than the feature it came with saved)
+            txt = open(out).read()
+            scratch = [(m.group(1), int(m.group(2))) for m in re.finditer(
+                r"\.amdhsa_kernel (\S+)\n(?:.*\n)*?\s*\.amdhsa_private_segment_fixed_size (\d+)", txt)]
+            spilled = [(n, b) for n, b in scratch if b > 0]
+            for n, b in spilled:
+                print("   %s: %d bytes of scratch per lane (register spill)" % (n, b))
+            bad += len(spilled)
+            print("%-22s %5d MFMAs, %d finding(s), %d of %d kernels with scratch" % (
+                os.path.basename(f), n_mfma, len(found), len(spilled), len(scratch)))
             for name, i, a, j, b, ws, need in found[:20]:
                 print("   %s\n     [%d] %s\n     [%d] %s   <- %d wait states later, needs %d" % (name, i, a, j, b, ws, need))
             bad += len(found)
