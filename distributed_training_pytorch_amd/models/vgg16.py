@@ -80,9 +80,18 @@ class ConvBlock(nn.Module):
             while i < len(mods):
                 m = mods[i]
                 if isinstance(m, (Conv3x3, ConvFirst)) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNormReLU):
-                    y = conv_bn_relu_folded(m, mods[i + 1], x)
+                    # the block's last triple is followed by (ReLU marker, MaxPool): the pool joins the kernel
+                    last = (i + 4 == len(mods) and isinstance(mods[i + 2], ReLUMarker) and not mods[i + 2].active
+                            and isinstance(mods[i + 3], MaxPool2x2))
+                    y = conv_bn_relu_folded(m, mods[i + 1], x, pool=last)
                     if y is not None:
-                        x, i = y, i + 2
+                        if last:
+                            x, pooled = y
+                            if pooled:
+                                return x
+                        else:
+                            x = y
+                        i += 2
                         continue
                 x = m(x)
                 i += 1

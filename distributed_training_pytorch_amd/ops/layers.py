@@ -701,10 +701,12 @@ class BatchNormReLU(FusedLayer):
         return "%d, eps=%g, momentum=%g, relu=%s" % (self.num_features, self.eps, self.momentum, self.relu)
 
 
-def conv_bn_relu_folded(conv, bn, x):
+def conv_bn_relu_folded(conv, bn, x, pool=False):
     """Inference: ``relu(bn(conv(x)))`` as ONE convolution kernel — the eval-mode scale is folded
     into the bf16 filter copy and scale/shift into the bias (cached until the weights or the
-    running statistics change), so BatchNorm costs nothing at evaluation time."""
+    running statistics change), so BatchNorm costs nothing at evaluation time.
+    ``pool``: the block's 2x2 max-pool follows; where the shapes allow it (64 input channels) it
+    joins the same kernel and ``(y, True)`` is returned, else ``(y, False)`` with y un-pooled."""
     arena = _arena_of(conv)
     key = (arena.lp_epoch, bn.running_mean._version, bn.running_var._version)
     cached = conv.__dict__.get("_bnfold")
@@ -720,7 +722,12 @@ def conv_bn_relu_folded(conv, bn, x):
         x = x.contiguous()
         if x.shape[1] != 3:
             return None
-        return K.conv1_fprop(x, wf, bf, bn.relu, conv.in_scale, conv.in_mean, conv.in_inv_std)
+        y = K.conv1_fprop(x, wf, bf, bn.relu, conv.in_scale, conv.in_mean, conv.in_inv_std)
+        return (y, False) if pool else y
+    if pool:
+        if bn.relu and x.dim() == 4 and K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2]):
+            return K.conv3x3_relu_pool_fprop(x, wf, bf)[0], True
+        return K.conv3x3_fprop(x, wf, bf, relu=bn.relu), False
     return K.conv3x3_fprop(x, wf, bf, relu=bn.relu)
 
 
