@@ -136,7 +136,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         arena = _arena_of(layer)
         # 1-bit ReLU masks: this layer packs (y > 0) for the data gradient of the NEXT convolution and
         # picks up the bits its producer left on x (tensor attribute set in Conv3x3.forward)
-        want_bits = K.relu_bitmask and layer.relu and layer.emit_relu_bits
+        want_bits = K.relu_bitmask and layer.relu and layer.emit_relu_bits and not layer.__dict__.get("_infer", False)
         # a training-mode BatchNorm follows: the epilogue leaves its batch statistics behind
         want_stats = bool(getattr(layer, "bn_follows", False)) and layer.training and not layer.relu
         y = K.conv3x3_fprop(x, arena.lp(weight), bias.detach() if bias is not None else None, relu=layer.relu,
@@ -285,6 +285,7 @@ class Conv3x3(_Conv3x3Derived, FusedLayer):
         if not x.is_cuda:
             y = F.conv2d(x, self.weight, self.bias, padding=1)
             return F.relu(y) if self.relu else y
+        self.__dict__["_infer"] = not torch.is_grad_enabled()     # no backward: no ReLU masks to leave behind
         y = _Conv3x3Fn.apply(x, self.weight, self.bias, self)
         bits = self.__dict__.pop("_bits_tmp", None)
         if bits is not None:
