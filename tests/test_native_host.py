@@ -35,3 +35,47 @@ def test_no_mfma_result_is_read_too_early_in_the_shipped_kernels():
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:]
     assert "conv_c64.hip" in r.stdout and "igemm.hip" in r.stdout
+    import re
+    counts = dict(re.findall(r"^(\S+\.hip)\s+(\d+) MFMAs", r.stdout, flags=re.M))
+    assert int(counts["igemm.hip"]) > 1000 and int(counts["conv_c64.hip"]) > 300, counts     # the parser really saw the kernels
+    assert " 0 of " in r.stdout and "kernels with scratch" in r.stdout
+
+
+def test_mfma_hazard_checker_flags_a_known_bad_sequence(tmp_path):
+    """The checker itself: a VALU read 2 wait states behind an MFMA across a branch is a finding, the
+    same read behind enough s_nops is not, an accumulation chain on the same registers is not, and a
+    kernel with scratch memory is reported (so a silent change of hipcc's output format cannot turn
+    the tree-wide check into a no-op: that one also asserts non-zero MFMA counts)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(ROOT, "bench", "check_mfma_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = """
+_Z3badv:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\ts_cbranch_vccnz .LBB0_2
+\tv_mov_b32_e32 v20, 0
+.LBB0_2:
+\ts_nop 0
+\tv_cvt_pk_bf16_f32 v4, v0, v1
+\ts_endpgm
+_Z4goodv:
+\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[12:15], v[0:3]
+\ts_cbranch_vccnz .LBB1_2
+\tv_mov_b32_e32 v20, 0
+.LBB1_2:
+\ts_nop 7
+\tv_cvt_pk_bf16_f32 v4, v0, v1
+\ts_endpgm
+"""
+    f = tmp_path / "k.s"
+    f.write_text(bad)
+    kernels = chk.parse(str(f))
+    assert set(kernels) == {"_Z3badv", "_Z4goodv"}
+    found_bad = chk.check_kernel("_Z3badv", *kernels["_Z3badv"])
+    found_good = chk.check_kernel("_Z4goodv", *kernels["_Z4goodv"])
+    assert found_good == []
+    assert len(found_bad) >= 1 and all(fd[0] == "_Z3badv" and "v_cvt_pk_bf16_f32" in fd[4] for fd in found_bad)
+    assert min(fd[5] for fd in found_bad) <= 3 and found_bad[0][6] == 7       # wait states seen / needed
+    assert chk.need_of("v_mfma_f32_32x32x16_bf16") > chk.need_of("v_mfma_f32_16x16x32_bf16")
