@@ -77,6 +77,10 @@ def self_launch(args, argv):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.share_device and args.gpus > 1 and (args.backend or "nccl") == "nccl" and args.device != "cpu":
+        # RCCL refuses two ranks on one device ("duplicate GPU"); say so before anything is spawned
+        raise SystemExit("--share-device rehearses the multi-process plumbing on ONE GPU and needs --backend gloo "
+                         "(RCCL cannot place two ranks on the same device)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, argv))
 
