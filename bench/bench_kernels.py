@@ -79,7 +79,7 @@ def main():
         if args.sweep:
             rec["fprop_sweep"] = best("igemm", lambda: k.conv3x3_fprop(x, w, b, True), [0, 3, 8, 16], [1])
             rec["dgrad_sweep"] = best("igemm", lambda: k.conv3x3_dgrad(dy, wd, mask_src=x), [0, 3, 8, 16], [1])
-            rec["wgrad_sweep"] = best("wgrad", lambda: k.conv3x3_wgrad(dy, x, gw), [0, 1, 2, 3, 4, 5], [4, 16, 64])
+            rec["wgrad_sweep"] = best("wgrad", lambda: k.conv3x3_wgrad(dy, x, gw), [2, 3, 8, 9], [4, 16, 64])
         if not args.no_stock:
             xs = x.permute(0, 3, 1, 2)          # NCHW view of NHWC memory == channels_last
             ws = w.view(Co, 3, 3, C).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)

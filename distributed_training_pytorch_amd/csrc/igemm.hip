@@ -360,6 +360,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int tap; long ka, kb;
       koffs(T, tap, ka, kb);
       const bool live = T < kend;
+#ifdef DTP_DIAG_SKIP_A_DX
+      // DIAGNOSTIC (wrong math): the dx = -1 / +1 taps reuse whatever A image is in the slot — the
+      // traffic of a kernel that stages one activation image per tap ROW (upper bound of that design)
+      if (TAPS9 && (tap % 3) != 1) return;
+#endif
       char* dst = smem + d * DB + h * SA + wave * 1024;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {

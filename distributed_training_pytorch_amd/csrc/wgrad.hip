@@ -1,4 +1,9 @@
-// Weight-gradient GEMM ("TT": both operands are reduction-major) for gfx950.
+// Weight-gradient GEMM ("TT": both operands are reduction-major) for gfx950 — the SMALL-TILE
+// configurations (cfg 2 / 3 / 4: 128x64, 64x128, 64x64) that serve outputs narrower than the
+// 128-/256-wide tiles of wgrad2.hip (linear3's [C x 4096] gradient, 64-channel layers of user models),
+// the split-K reduce kernel and the dispatcher of both files.  The 256x256 / 128x128 tiles and the
+// software-pipelined variants that lived here in rounds 1-2 were superseded by wgrad2.hip (asm
+// transposed reads, descriptor staging) and are gone.
 //
 //   dW[m][tap*C + c] = sum_k  dY[k][m] * X[pix(k) + shift(tap)][c]          (3x3 conv, TAPS9)
 //   dW[m][n]         = sum_k  dY[k][m] * X[k][n]                            (linear)
@@ -20,7 +25,6 @@
 // Reference parity: replaces cuDNN bwd-filter and the cuBLAS dW GEMMs
 // triggered by loss.backward() at example_trainer.py:86.
 #include "dtp_common.h"
-#include <type_traits>
 
 struct WgradParams {
   const char* dY;     // [K][lda] bf16
@@ -43,7 +47,7 @@ DTP_DEVINL int s_of(int k) {   // swizzle (in 16-B chunks) of LDS row k for an i
   return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, bool SWP = false>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9>
 __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradParams p) {
   constexpr int T = WGM * WGN * 64;
   constexpr int BK = 64;
@@ -195,60 +199,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt_kernel(const WgradPar
     }
   };
 
-  // SWP: the K-step is cut into (k-substep x m-half) sub-steps; the transposed fragment reads of
-  // sub-step s+1 are issued before the MFMAs of sub-step s, so only the first sub-step's reads
-  // (16 instead of 2 x 24 ds_read_b64_tr_b16 per wave) stay exposed after the barrier.
-  auto compute_swp = [&](int buf) {
-    constexpr int MH = MI >= 2 ? 2 : 1;
-    constexpr int MIH = MI / MH;
-    constexpr int NSUB = 2 * MH;
-    const char* bA = smem + buf * STAGE;
-    const char* bB = bA + BK * RBA;
-    bf16x8_t xa[2][MIH], wb[2][NI];
-#define WG_TRD(dst, addr, RB_)                                                                   \
-  {                                                                                              \
-    const s4 lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(addr));             \
-    const s4 hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)((addr) + 4 * RB_)); \
-    dst = (bf16x8_t){lo_[0], lo_[1], lo_[2], lo_[3], hi_[0], hi_[1], hi_[2], hi_[3]};            \
-  }
-#pragma unroll
-    for (int i = 0; i < MIH; ++i)
-      WG_TRD(xa[0][i], bA + krow * RBA + ((((a_cw + 2 * i) ^ sa) + sub) << 4) + half8, RBA)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-      WG_TRD(wb[0][j], bB + krow * RBB + ((((b_cw + 2 * j) ^ sb) + sub) << 4) + half8, RBB)
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-      const int ks = s / MH, mh = s % MH;
-      if (s + 1 < NSUB) {
-        const int ks1 = (s + 1) / MH, mh1 = (s + 1) % MH;
-#pragma unroll
-        for (int i = 0; i < MIH; ++i)
-          WG_TRD(xa[(s + 1) & 1][i],
-                 bA + (ks1 * 32 + krow) * RBA + ((((a_cw + 2 * (mh1 * MIH + i)) ^ sa) + sub) << 4) + half8, RBA)
-        if (ks1 != ks) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            WG_TRD(wb[ks1 & 1][j], bB + (ks1 * 32 + krow) * RBB + ((((b_cw + 2 * j) ^ sb) + sub) << 4) + half8, RBB)
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < MIH; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[mh * MIH + i][j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks & 1][j], xa[s & 1][i], acc[mh * MIH + i][j], 0, 0, 0);
-    }
-#undef WG_TRD
-  };
-
   if (kbeg < kend) stage(kbeg, 0);
   int buf = 0;
   for (int kt = kbeg; kt < kend; ++kt) {
     sync_lds_dma();      // stage kt landed everywhere; everyone is done reading the other buffer
     if (kt + 1 < kend) stage(kt + 1, buf ^ 1);
-    if (SWP) compute_swp(buf);
-    else compute(buf);
+    compute(buf);
     buf ^= 1;
   }
 
@@ -321,7 +277,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nspli
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, bool SWP = false>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9>
 static int launch_wg(const WgradParams& p0, int nsplit, hipStream_t stream) {
   WgradParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -333,7 +289,7 @@ static int launch_wg(const WgradParams& p0, int nsplit, hipStream_t stream) {
   }
   constexpr int lds = 2 * 64 * (BM + BN) * 2;
   static bool attr_set = false;
-  auto kern = wgrad_tt_kernel<BM, BN, WGM, WGN, TAPS9, SWP>;
+  auto kern = wgrad_tt_kernel<BM, BN, WGM, WGN, TAPS9>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -2;
@@ -375,15 +331,9 @@ extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* par
 #define DTP_WG(BM_, BN_, WGM_, WGN_) \
   (t9 ? launch_wg<BM_, BN_, WGM_, WGN_, true>(p, nsplit, stream) : launch_wg<BM_, BN_, WGM_, WGN_, false>(p, nsplit, stream))
   switch (cfg) {
-    case 0: rc = DTP_WG(256, 256, 2, 4); break;
-    case 1: rc = DTP_WG(128, 128, 2, 2); break;
     case 2: rc = DTP_WG(128, 64, 2, 2); break;
     case 3: rc = DTP_WG(64, 128, 2, 2); break;
     case 4: rc = DTP_WG(64, 64, 2, 2); break;
-    case 6: rc = t9 ? launch_wg<256, 256, 2, 4, true, true>(p, nsplit, stream)
-                    : launch_wg<256, 256, 2, 4, false, true>(p, nsplit, stream); break;
-    case 7: rc = t9 ? launch_wg<128, 128, 2, 2, true, true>(p, nsplit, stream)
-                    : launch_wg<128, 128, 2, 2, false, true>(p, nsplit, stream); break;
     case 8: case 9:
       if (t9 && (C % (cfg == 8 ? 256 : 128))) return -20;
       rc = dtp_wgrad_tt2_launch(dY, X, out, partial, K, M, Ntot, C, taps, H, W, lda, ldb, out_fp32, beta, nsplit,

@@ -20,8 +20,7 @@ N_CU = 256
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
-WGRAD_TILES = {0: (256, 256), 1: (128, 128), 2: (128, 64), 3: (64, 128), 4: (64, 64),
-               6: (256, 256), 7: (128, 128),   # 6/7: software-pipelined fragment reads (5 was an 8-phase port: slower, deleted)
+WGRAD_TILES = {2: (128, 64), 3: (64, 128), 4: (64, 64),    # wgrad.hip: small-tile fallbacks (narrow outputs)
                8: (256, 256), 9: (128, 128)}   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
@@ -86,13 +85,13 @@ def pick_wgrad(M, C, taps, ksteps):
         return _overrides["wgrad"](M, C, taps, ksteps)
     if taps == 9:
         # cfg 8 / 9 (wgrad2.hip): the LDS-DMA of the next K-tile stays in flight under the MFMAs
-        # (hipcc drains it in front of the builtin transposed reads of cfg 0-7): 1.13-1.18 PF/s vs
+        # (hipcc drains it in front of builtin transposed reads, the round-1 kernels): 1.13-1.18 PF/s vs
         # 0.89-0.95 on the 256/512-channel layers, 0.92-0.97 vs 0.69 on the 128-channel ones
         # (batch 256, bench/bench_wgrad2.py, profiles/23_*)
         if M >= 256 and C % 256 == 0:
-            cfg = 8 if wgrad2 else 6
+            cfg = 8
         elif M >= 128 and C % 128 == 0:
-            cfg = 9 if wgrad2 else 1
+            cfg = 9
         elif M >= 128:
             cfg = 2
         elif C % 128 == 0:
@@ -101,9 +100,9 @@ def pick_wgrad(M, C, taps, ksteps):
             cfg = 4
     else:
         if M >= 256 and C >= 256:
-            cfg = 8 if wgrad2 else 0
+            cfg = 8
         elif M >= 128:
-            cfg = (9 if wgrad2 else 1) if C >= 128 else 2
+            cfg = 9 if C >= 128 else 2
         else:
             cfg = 3 if C >= 128 else 4
     bm, bn = WGRAD_TILES[cfg]
@@ -168,7 +167,6 @@ fuse_colsum = True      # tests flip this to compare against the stand-alone col
 two_pass_c128 = _os.environ.get("DTP_DGRAD_TWO_PASS", "0") == "1"
 igemm_512 = _os.environ.get("DTP_IGEMM_512", "1") != "0"              # A/B switch: 512x128 8-phase tile
 relu_bitmask = _os.environ.get("DTP_RELU_BITMASK", "1") != "0"        # A/B switch: 1-bit ReLU masks for dgrad
-wgrad2 = _os.environ.get("DTP_WGRAD2", "1") != "0"                    # A/B switch: second-generation weight-gradient kernels
 
 
 def colsum_parts(parts, nparts, C, out, n_valid=None, beta=0.0):

@@ -140,7 +140,7 @@ def test_conv3x3_wgrad(shape, out_dtype):
     _close(out, 2 * ref, 3e-2, 3e-2 * scale, "wgrad-acc%s" % (shape,))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [2, 3, 4, 8, 9])
 def test_conv3x3_wgrad_all_tile_configs(cfg):
     k = _k()
     torch.manual_seed(4)
