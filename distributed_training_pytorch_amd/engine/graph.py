@@ -29,11 +29,12 @@ when ``--hip-graph`` is passed — it is opt-in.
 """
 import torch
 
+from ..ops import rng as _rng
 from ..ops.layers import Linear
 
 
 class GraphedTrainStep(object):
-    _SEED_STEP = 0x5851F42D4C957F2D & (2 ** 62 - 1)
+    _SEED_STEP = _rng.STEP
 
     def __init__(self, model, criterion, optimizer, warmup=2, enabled=True):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
@@ -50,6 +51,8 @@ class GraphedTrainStep(object):
         self.enabled = (bool(enabled) and torch.cuda.is_available() and self.arena is not None
                         and (world == 1 or self.distributed) and getattr(optimizer, "graph_safe", False))
         self._seed = None
+        self._seed_calls = 0
+        self.rng = getattr(self.raw, "dropout_rng", None) or _rng.DropoutRng()
         self._eager_left = 0
 
     # ------------------------------------------------------------------ helpers
@@ -67,8 +70,15 @@ class GraphedTrainStep(object):
 
     def _attach_seed(self, device):
         if self._seed is None:
+            # device copy of the model's dropout state (ops/rng.py): base + calls * STEP.  From here on
+            # the captured add advances it; the host counter follows in __call__ so that snapshots and
+            # the eager path see the same number
             self._seed = torch.zeros(1, dtype=torch.int64, device=device)
-            self._seed.fill_(torch.initial_seed() & (2 ** 62 - 1))
+            self._seed.fill_(self.rng.device_value())
+            self._seed_calls = self.rng.calls
+        elif self._seed_calls != self.rng.calls:         # a snapshot was loaded / someone ran the model eagerly
+            self._seed.fill_(self.rng.device_value())
+            self._seed_calls = self.rng.calls
         for m in self.raw.modules():
             if isinstance(m, Linear):
                 m.device_seed = self._seed
@@ -99,20 +109,26 @@ class GraphedTrainStep(object):
         next call captures, and every later one is a single graph launch."""
         if not self.enabled or not x.is_cuda:
             return self._eager(x, y)
-        self._attach_seed(x.device)
         key = self._hyper_key(x, y)
         if key != self._key or (self.graph is not None and self.arena._versions() != self._versions):
             self.graph, self._key, self._eager_left = None, key, max(1, self.warmup)
+            self._seed_calls = -1                      # re-derive the device copy of the dropout state
+        self._attach_seed(x.device)
         if self.graph is None:
             if self._eager_left > 0:
                 self._eager_left -= 1
                 self._seed.add_(self._SEED_STEP)
-                return self._eager(x, y)
+                loss = self._eager(x, y)               # (the model's forward advanced rng.calls)
+                self._seed_calls = self.rng.calls
+                return loss
             self.arena.refresh_lp()
-            self._capture(x, y)
+            self._capture(x, y)                        # ran the forward's Python once: rng.calls advanced
         else:
             self.x_static.copy_(x, non_blocking=True)
             self.y_static.copy_(y, non_blocking=True)
+            if self.raw.training:
+                self.rng.advance()                     # the replayed add advances the device copy
+        self._seed_calls = self.rng.calls
         self.graph.replay()
         self.replays += 1
         # host-side bookkeeping that the eager path does per step

@@ -29,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from ..ops.layers import FusedLayer
+from ..ops.rng import DropoutRng
 from .param_arena import ParamArena
 
 
@@ -38,9 +39,15 @@ def attach_arena(module, grad_dtype=torch.float32):
     arena = ParamArena(module, grad_dtype=grad_dtype)
     object.__setattr__(module, "param_arena", arena)
     on_gpu = arena.device.type == "cuda"
-    for m in module.modules():
+    rng = getattr(module, "dropout_rng", None)
+    if rng is None:
+        rng = DropoutRng()
+        object.__setattr__(module, "dropout_rng", rng)
+    for index, m in enumerate(module.modules()):
         if isinstance(m, FusedLayer):
             object.__setattr__(m, "_arena", arena)
+            if hasattr(m, "_seed_salt"):          # dropout layers: key = f(run rng, position in the model)
+                m._rng, m._seed_salt = rng, DropoutRng.salt_for(index)
             if on_gpu:
                 for p in m.parameters(recurse=False):
                     arena.kernel_written.add(id(p))
@@ -63,6 +70,9 @@ class FusedModel(nn.Module):
         self.grad_dtype = grad_dtype
         self.param_arena = None
         self._finalized = False
+        # dropout masks are a function of (seed, rank, training-forward number, layer): ops/rng.py;
+        # the Trainer seeds it, snapshots carry it
+        self.dropout_rng = DropoutRng()
 
     def finalize(self):
         """Call at the end of ``__init__``: all parameters exist, build the arena."""
@@ -103,6 +113,8 @@ class FusedModel(nn.Module):
         self._attach_arena()
 
     def prepare_input(self, x):
+        if self.training:
+            self.dropout_rng.advance()       # one call number per training forward (micro-step)
         if x.is_cuda and self.param_arena is not None:
             self.param_arena.refresh_lp()
             from ..ops import layers as L

@@ -15,7 +15,6 @@ Fusion contracts:
   * weight/bias gradients are written by the kernels straight into the gradient arena
     (overwrite-on-first-write), the reducer is notified per parameter.
 """
-import itertools
 import os
 
 import torch
@@ -23,9 +22,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import kernels as K
+from .rng import DropoutRng
 
 BF16 = torch.bfloat16
-_seed_counter = itertools.count(1)
+# dropout layers used outside a FusedModel (tests, ad-hoc modules) share this state; models own theirs
+_default_rng = DropoutRng()
 
 # run each conv layer's weight gradient on a side stream, concurrently with its data gradient
 OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
@@ -559,7 +560,11 @@ class Linear(_LinearDerived, FusedLayer):
         # hipGraph replay: kernel arguments are frozen at capture, so the dropout seed must come
         # from device memory (engine.graph.GraphedTrainStep advances it inside the graph)
         self.device_seed = None
-        self._seed_salt = next(_seed_counter) * 0x9E3779B97F4A7C15 & (2 ** 62 - 1)
+        # mask key = f(seed, rank, forward-call number of the model, this salt): ops/rng.py.  The salt is
+        # the layer's position inside its model (models.fused_model.attach_arena re-assigns it), so it
+        # is the same in every process and after every re-creation of the model
+        self._seed_salt = DropoutRng.salt_for(0)
+        self._rng = None
 
     def _input_mask_scale(self):
         if self.input_is_relu_out and self.input_drop_p > 0 and self.training:
@@ -577,7 +582,13 @@ class Linear(_LinearDerived, FusedLayer):
         p = self.drop_p if self.training else 0.0
         if p > 0 and self.device_seed is not None:
             return _LinearFn.apply(x, self.weight, self.bias, self, p, self._seed_salt, self.device_seed)
-        seed = (torch.initial_seed() * 1000003 + next(_seed_counter)) & (2 ** 63 - 1) if p > 0 else 0
+        seed = 0
+        if p > 0:
+            rng = self._rng
+            if rng is None:                      # stand-alone layer: every forward is a new call
+                rng = _default_rng
+                rng.advance()
+            seed = rng.key(self._seed_salt)
         return _LinearFn.apply(x, self.weight, self.bias, self, p, seed)
 
 

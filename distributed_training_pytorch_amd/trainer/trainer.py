@@ -134,8 +134,17 @@ class Trainer(object):
         self.use_hip_graph = bool(use_hip_graph)
         self.graphed_step = None
 
+        # RNG is part of the run state: ``seed`` seeds torch (weight init, CPU dropout, augmentation
+        # draws of datasets that use the global generator) and keys the GPU dropout masks together
+        # with (rank, step, layer) — ops/rng.py.  The reference never seeds (model/vgg16.py:40).
+        if seed is not None:
+            torch.manual_seed(int(seed))
+
         # T3/T6 model on its device first, then criterion / optimizer / scheduler
         self.model = self.build_model().to(self.device)
+        rng = getattr(self.model, "dropout_rng", None)
+        if rng is not None and seed is not None:
+            rng.seed = int(seed)
         self.criterion = self.build_criterion()
         self.optimizer = self.build_optimizer()
         self.scheduler = self.build_scheduler()
@@ -199,7 +208,7 @@ class Trainer(object):
     def _save_snapshot(self, epoch, name="last"):
         path = os.path.join(self.save_weight_folder, "%s.pth" % name)
         extra = dict(best_fitness=copy.deepcopy(self.best_fitness), global_step=self.global_step,
-                     framework="distributed_training_pytorch_amd")
+                     rng_state=self._rng_state(), framework="distributed_training_pytorch_amd")
         ckpt.save_snapshot(path, epoch, self.raw_model, self.optimizer, self.scheduler, extra)
         self.log("Saved model at epoch %d!" % epoch, log_type="info")
 
@@ -215,7 +224,28 @@ class Trainer(object):
         if isinstance(bf, dict) and "epoch" in bf:
             self.best_fitness = bf
         self.global_step = int(snap.get("global_step", 0))
+        self._load_rng_state(snap.get("rng_state"))
         self.log("Resumed from %s at epoch %d" % (path, self.cur_epoch), log_type="info")
+
+    def _rng_state(self):
+        """What makes a resumed run draw the numbers the uninterrupted run would have drawn: the
+        dropout call counter of the model (ops/rng.py; rank 0's — all ranks advance in lock step) and
+        torch's CPU generator.  Extra snapshot key: old readers ignore it."""
+        state = dict(torch_cpu=torch.get_rng_state())
+        rng = getattr(self.raw_model, "dropout_rng", None)
+        if rng is not None:
+            state.update(rng.state_dict())
+        return state
+
+    def _load_rng_state(self, state):
+        if not isinstance(state, dict):
+            return
+        rng = getattr(self.raw_model, "dropout_rng", None)
+        if rng is not None:
+            rng.load_state_dict(state)
+        t = state.get("torch_cpu")
+        if torch.is_tensor(t) and t.dtype == torch.uint8:
+            torch.set_rng_state(t.cpu())
 
     # ------------------------------------------------------------------ helpers for hooks
     def should_sync(self, micro_step):

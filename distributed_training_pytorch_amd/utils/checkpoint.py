@@ -4,8 +4,10 @@ Parity target: reference ``trainer/trainer.py:85-101`` — one ``torch.save`` fi
 the keys ``epoch``, ``model_state_dict`` (unwrapped module, fp32), ``optimizer_state_dict``,
 ``scheduler_state_dict`` under ``<save_folder>/weights/<name>.pth``.
 
-Additions that old readers ignore: ``best_fitness`` (quirk #7), ``rng_state``,
-``framework``.  Writes are atomic (tmp + ``os.replace``).  Loading ALWAYS uses
+Additions that old readers ignore: ``best_fitness`` (quirk #7), ``global_step``,
+``rng_state`` (written by ``Trainer._rng_state``: the model's dropout seed + call counter of
+``ops/rng.py`` and torch's CPU generator state — a resumed run draws the masks the uninterrupted
+run would have drawn) and ``framework``.  Writes are atomic (tmp + ``os.replace``).  Loading ALWAYS uses
 ``weights_only=True`` — a snapshot is data, never code: the one non-tensor type our files carry
 (``collections.Counter`` for ``MultiStepLR.milestones``) is allow-listed explicitly, and a file the
 safe loader refuses is an error unless the caller opts in with ``trusted=True`` (a file they wrote

@@ -419,6 +419,66 @@ def test_hip_graph_step_matches_eager_and_redraws_dropout():
     assert len(set(losses[1:])) >= 6                  # every replay drew a fresh dropout mask
 
 
+def test_dropout_rng_is_run_state_resume_is_bit_exact_and_ranks_differ(tmp_path):
+    """Dropout key = (seed, rank, forward-call number, layer) — ops/rng.py, reference model/vgg16.py:40,73-76:
+    (a) train 4 steps == train 2 + snapshot + fresh model/optimizer + resume + 2, bit for bit, dropout 0.3;
+    (b) the hipGraph step draws the SAME masks as the eager path (device copy of the same state);
+    (c) two ranks draw different masks, two models with the same (seed, rank) the same ones."""
+    from distributed_training_pytorch_amd.engine.graph import GraphedTrainStep
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    from distributed_training_pytorch_amd.utils import checkpoint as ckpt
+    torch.manual_seed(31)
+    xs = [torch.randn(4, 3, 32, 32, device="cuda") for _ in range(6)]
+    ys = [torch.randint(0, 3, (4,), device="cuda") for _ in range(6)]
+
+    def make(rank=0):
+        torch.manual_seed(32)
+        m = VGG16(3, 3, True, dropout=0.3).to("cuda").train()
+        m.dropout_rng.seed, m.dropout_rng.rank = 1234, rank
+        return m, FusedSGD(m, lr=0.002, momentum=0.9, weight_decay=1e-4), SoftmaxCrossEntropy()
+
+    def steps(m, o, c, lo, hi):
+        out = []
+        for x, y in zip(xs[lo:hi], ys[lo:hi]):
+            o.zero_grad()
+            loss = c(m(x), y)
+            loss.backward()
+            o.step()
+            out.append(float(loss.detach()))
+        return out
+
+    m1, o1, c1 = make()
+    ref = steps(m1, o1, c1, 0, 4)
+    # (a) resume
+    m2, o2, c2 = make()
+    got = steps(m2, o2, c2, 0, 2)
+    path = str(tmp_path / "mid.pth")
+    ckpt.save_snapshot(path, 0, m2, o2, None, extra=dict(rng_state=m2.dropout_rng.state_dict()))
+    snap = ckpt.load_snapshot(path)
+    m3, o3, c3 = make()
+    m3.dropout_rng.seed = 999                        # must come back from the snapshot
+    m3.load_state_dict(snap["model_state_dict"])
+    o3.load_state_dict(snap["optimizer_state_dict"])
+    m3.dropout_rng.load_state_dict(snap["rng_state"])
+    got += steps(m3, o3, c3, 2, 4)
+    assert got == ref, (got, ref)
+    assert torch.equal(m1.param_arena.flat_master, m3.param_arena.flat_master)
+    # (b) hipGraph == eager with dropout on
+    m4, o4, c4 = make()
+    g = GraphedTrainStep(m4, c4, o4, warmup=1)
+    lg = [float(g(x, y)) for x, y in zip(xs[:4], ys[:4])]
+    assert g.captures == 1 and g.replays == 3
+    assert lg == ref, (lg, ref)
+    assert torch.equal(m1.param_arena.flat_master, m4.param_arena.flat_master)
+    assert m4.dropout_rng.calls == m1.dropout_rng.calls == 4
+    # (c) ranks
+    m5, o5, c5 = make(rank=1)
+    other = steps(m5, o5, c5, 0, 1)
+    assert other[0] != ref[0], "rank 1 drew rank 0's dropout mask"
+
+
 def test_hip_graph_step_matches_eager_vgg16_bn():
     """VGG16-BN under GraphedTrainStep == eager, bit for bit, running statistics included: the
     BatchNorm statistic hand-overs (producer epilogue -> bn.hip, host-side slots) are decided at

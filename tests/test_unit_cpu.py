@@ -453,3 +453,46 @@ def test_clahe_algorithm():
     ramp = np.tile(np.arange(224, dtype=np.uint8), (224, 1))
     r = clahe(ramp, 2.0).astype(int)
     assert (np.diff(r[:, 4:24], axis=1) >= 0).all()
+
+
+def test_dropout_rng_keys_and_state_roundtrip():
+    """ops/rng.py: keys differ per rank / call / layer, are reproducible, and the device-side value
+    (base + calls*STEP) plus the salt equals the eager key in 64-bit wrap-around arithmetic."""
+    from distributed_training_pytorch_amd.ops.rng import MASK64, DropoutRng
+    a, b, c = DropoutRng(seed=7, rank=0), DropoutRng(seed=7, rank=1), DropoutRng(seed=7, rank=0)
+    s0, s1 = DropoutRng.salt_for(3), DropoutRng.salt_for(4)
+    assert a.key(s0) == c.key(s0) != b.key(s0)
+    assert a.key(s0) != a.key(s1)
+    k0 = a.key(s0)
+    a.advance()
+    assert a.key(s0) != k0
+    for _ in range(1000):
+        a.advance()
+    assert (a.device_value() + s0) & MASK64 == a.key(s0)
+    assert -(1 << 63) <= a.device_value() < (1 << 63)
+    st = a.state_dict()
+    d = DropoutRng(seed=1, rank=0)
+    d.load_state_dict(st)
+    assert d.calls == a.calls == 1001 and d.key(s1) == a.key(s1)
+
+
+def test_snapshot_carries_rng_state_and_trainer_seeds_torch(tmp_path):
+    """Trainer(seed=) seeds torch and the model's dropout state; ``last.pth`` carries ``rng_state``
+    (dropout seed + call counter + torch CPU generator) and a resumed Trainer restores it."""
+    from distributed_training_pytorch_amd.trainer.example_trainer import ExampleTrainer
+    from distributed_training_pytorch_amd.utils.checkpoint import load_snapshot
+    kw = dict(train_path="synthetic:8", val_path="synthetic:4", labels=["a", "b", "c"], height=32, width=32,
+              batch_size=4, pin_memory=False, have_validate=True, save_best_for=("accuracy", "geq"), save_period=1,
+              save_folder=str(tmp_path / "runs"), progress=False, lr=0.01, device="cpu")
+    tr = ExampleTrainer(max_epoch=1, seed=5, **kw)
+    w0 = tr.raw_model.param_arena.flat_master.clone()
+    assert tr.raw_model.dropout_rng.seed == 5
+    tr.train()
+    snap = load_snapshot(str(tmp_path / "runs" / "weights" / "last.pth"))
+    rs = snap["rng_state"]
+    assert rs["seed"] == 5 and rs["dropout_calls"] == 2 and rs["torch_cpu"].dtype == torch.uint8
+    tr2 = ExampleTrainer(max_epoch=2, seed=5, snapshot_path=str(tmp_path / "runs" / "weights" / "last.pth"), **kw)
+    assert tr2.raw_model.dropout_rng.calls == 2
+    assert torch.equal(torch.get_rng_state(), rs["torch_cpu"])
+    tr3 = ExampleTrainer(max_epoch=1, seed=5, **dict(kw, save_folder=str(tmp_path / "runs3")))
+    assert torch.equal(tr3.raw_model.param_arena.flat_master, w0), "same seed must give the same initial weights"
