@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--fp8-classifier", action="store_true", help="linear1/linear2 GEMMs in OCP e4m3 (config 5)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + per-bucket sharded SGD + all-gather instead of all-reduce + replicated SGD")
+    ap.add_argument("--no-bucket-optimizer", action="store_true",
+                    help="N > 1: run the fused SGD as one pass after the last gradient bucket instead of per "
+                         "bucket behind its all-reduce (the default; parallel/reducer.py)")
     return ap.parse_args(argv)
 
 
@@ -138,7 +141,9 @@ def main(argv=None):
                   fp8_classifier=args.fp8_classifier).to(dev)
     opt = FusedSGD(model, lr=args.lr, momentum=0.9, weight_decay=1e-4)
     crit = SoftmaxCrossEntropy()
-    dp = DataParallel(model, shard_optimizer=opt if args.shard_optimizer else None)
+    per_bucket = not args.shard_optimizer and not args.no_bucket_optimizer
+    dp = DataParallel(model, shard_optimizer=opt if args.shard_optimizer else None,
+                      bucket_optimizer=opt if per_bucket else None)
     dp.train()
     if args.grad_accum < 1 or args.batch_per_gpu % args.grad_accum:
         raise SystemExit("--batch-per-gpu must be a multiple of --grad-accum")

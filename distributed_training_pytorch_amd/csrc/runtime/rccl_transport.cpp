@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <deque>
 #include <mutex>
 #include <vector>
 
@@ -26,20 +27,34 @@ struct Transport {
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
   int rank = 0, world = 1, device = 0;
-  std::vector<hipEvent_t> events;   // ring of reusable events
-  size_t next_event = 0;
+  // Reusable events, oldest first.  An event is re-recorded only after hipEventQuery says the work
+  // it marks has completed; while the oldest is still pending (a pass with more than kRing / 3
+  // buckets in sharded mode, a slow collective) the pool GROWS instead — re-recording a live event
+  // would silently move the point a waiting stream is released at.  Events recorded while a stream
+  // is being captured into a hipGraph belong to that graph for good and are never reused.
+  static constexpr size_t kRing = 64;
+  std::deque<hipEvent_t> events;
+  std::vector<hipEvent_t> graph_events;
   unsigned long long launched = 0, bytes = 0;
   std::mutex mu;
 
-  hipEvent_t event() {
-    if (events.size() < 64) {
-      hipEvent_t e;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+  }
+
+  hipEvent_t event(hipStream_t recorded_on) {
+    const bool cap = capturing(recorded_on) || capturing(comm_stream);
+    if (!cap && events.size() >= kRing && hipEventQuery(events.front()) == hipSuccess) {
+      hipEvent_t e = events.front();
+      events.pop_front();
       events.push_back(e);
       return e;
     }
-    hipEvent_t e = events[next_event % events.size()];
-    ++next_event;
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (cap) graph_events.push_back(e);
+    else events.push_back(e);
     return e;
   }
 };
@@ -143,7 +158,7 @@ int dtp_rccl_allreduce_async(void* h, void* buf, size_t count, int dtype_kind, i
   auto* t = static_cast<Transport*>(h);
   if (!t || !buf || count == 0) return -2;
   std::lock_guard<std::mutex> lk(t->mu);
-  hipEvent_t ready = t->event();
+  hipEvent_t ready = t->event(producer_stream);
   if (!ready) return -3;
   DTP_HIP(hipEventRecord(ready, producer_stream));
   DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
@@ -162,7 +177,7 @@ int dtp_rccl_reduce_scatter_async(void* h, void* buf, size_t count, int dtype_ki
   std::lock_guard<std::mutex> lk(t->mu);
   const size_t S = count / (size_t)t->world, esz = dtype_kind == 1 ? 2 : 4;
   if (producer_stream != t->comm_stream) {
-    hipEvent_t ready = t->event();
+    hipEvent_t ready = t->event(producer_stream);
     if (!ready) return -3;
     DTP_HIP(hipEventRecord(ready, producer_stream));
     DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
@@ -183,7 +198,7 @@ int dtp_rccl_all_gather_async(void* h, void* buf, size_t count, int dtype_kind, 
   std::lock_guard<std::mutex> lk(t->mu);
   const size_t S = count / (size_t)t->world, esz = dtype_kind == 1 ? 2 : 4;
   if (!on_comm_stream) {
-    hipEvent_t ready = t->event();
+    hipEvent_t ready = t->event(producer_stream);
     if (!ready) return -3;
     DTP_HIP(hipEventRecord(ready, producer_stream));
     DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
@@ -205,7 +220,7 @@ int dtp_rccl_wait(void* h, hipStream_t consumer_stream) {
   auto* t = static_cast<Transport*>(h);
   if (!t) return -2;
   std::lock_guard<std::mutex> lk(t->mu);
-  hipEvent_t done = t->event();
+  hipEvent_t done = t->event(consumer_stream);
   if (!done) return -3;
   DTP_HIP(hipEventRecord(done, t->comm_stream));
   DTP_HIP(hipStreamWaitEvent(consumer_stream, done, 0));
@@ -216,12 +231,12 @@ int dtp_rccl_broadcast(void* h, void* buf, size_t count, int dtype_kind, int roo
   auto* t = static_cast<Transport*>(h);
   if (!t || !buf) return -2;
   std::lock_guard<std::mutex> lk(t->mu);
-  hipEvent_t ready = t->event();
+  hipEvent_t ready = t->event(stream);
   if (!ready) return -3;
   DTP_HIP(hipEventRecord(ready, stream));
   DTP_HIP(hipStreamWaitEvent(t->comm_stream, ready, 0));
   DTP_NCCL(ncclBroadcast(buf, buf, count, dtype_of(dtype_kind), root, t->comm, t->comm_stream));
-  hipEvent_t done = t->event();
+  hipEvent_t done = t->event(stream);
   if (!done) return -3;
   DTP_HIP(hipEventRecord(done, t->comm_stream));
   DTP_HIP(hipStreamWaitEvent(stream, done, 0));
@@ -243,11 +258,20 @@ int dtp_rccl_stats(void* h, unsigned long long* launched, unsigned long long* by
   return 0;
 }
 
+// events currently owned by the transport (reusable pool + hipGraph-owned): for tests and leak checks
+int dtp_rccl_event_count(void* h) {
+  auto* t = static_cast<Transport*>(h);
+  if (!t) return -2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  return (int)(t->events.size() + t->graph_events.size());
+}
+
 int dtp_rccl_destroy(void* h) {
   auto* t = static_cast<Transport*>(h);
   if (!t) return 0;
   hipStreamSynchronize(t->comm_stream);
   for (hipEvent_t e : t->events) hipEventDestroy(e);
+  for (hipEvent_t e : t->graph_events) hipEventDestroy(e);
   ncclCommDestroy(t->comm);
   hipStreamDestroy(t->comm_stream);
   delete t;
@@ -296,6 +320,8 @@ struct DtpReducer {
   unsigned long long passes = 0, launched = 0, duplicate_notifications = 0;
   // sharded optimizer
   int opt_kind = 0;                 // 0: all-reduce mode; 1: SGD; 2: AdamW
+  int shard_world = 0;              // optimizer-in-scheduler modes: 1 = replicated (all-reduce, then the whole
+                                    // bucket is updated on every rank), > 1 = sharded over that many ranks
   dtp_sgd_fn sgd = nullptr;
   dtp_adamw_fn adamw = nullptr;
   std::vector<DtpShard> shards;
@@ -313,7 +339,12 @@ static int launch_bucket(DtpReducer* r, int bi, hipStream_t producer_stream) {
   if (r->opt_kind == 0)
     return dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream);
   if (!r->pass_armed) return -30;      // begin_pass() must precede the first launch of a pass
-  int rc = dtp_rccl_reduce_scatter_async(r->transport, b.ptr, b.count, b.dtype_kind, producer_stream);
+  // replicated mode (the default data-parallel path): all-reduce, then the fused optimizer updates the
+  // WHOLE bucket on the communication stream — the 0.5 ms optimizer pass over 134 M parameters hides
+  // under the rest of backward bucket by bucket instead of running after the last collective
+  int rc = r->shard_world == 1
+               ? dtp_rccl_allreduce_async(r->transport, b.ptr, b.count, b.dtype_kind, 1, producer_stream)
+               : dtp_rccl_reduce_scatter_async(r->transport, b.ptr, b.count, b.dtype_kind, producer_stream);
   if (rc != 0) return rc;
   const DtpShard& sh = r->shards[bi];
   hipStream_t cs = (hipStream_t)dtp_rccl_comm_stream(r->transport);
@@ -325,6 +356,7 @@ static int launch_bucket(DtpReducer* r, int bi, hipStream_t producer_stream) {
     rc = r->adamw(sh.master, sh.grad, b.dtype_kind == 1, sh.s1, sh.s2, sh.lp, sh.n, h[0], h[1], h[2], h[3], h[4], 1.0f,
                   r->iargs[0], cs);
   if (rc != 0) return rc < 0 ? rc : -rc;
+  if (r->shard_world == 1) return 0;   // every rank updated every element: nothing to gather
   return dtp_rccl_all_gather_async(r->transport, sh.wbase, sh.wcount, r->wkind, cs, 1);
 }
 
@@ -406,8 +438,10 @@ int dtp_reducer_finalize(void* h, hipStream_t stream) {
   return n;
 }
 
-// Switch the scheduler to sharded mode.  Arrays have one entry per bucket; the slice pointers
-// address THIS rank's 1/world of the bucket.  opt_kind 1 = SGD (s2 unused), 2 = AdamW.
+// Switch the scheduler to an optimizer-in-scheduler mode.  Arrays have one entry per bucket; the
+// slice pointers address THIS rank's 1/world of the bucket.  opt_kind 1 = SGD (s2 unused), 2 = AdamW.
+// world == 1: replicated — all-reduce + update of the whole bucket on every rank, no all-gather
+// (whatever the communicator's size); world > 1: reduce-scatter + owned slice + all-gather.
 int dtp_reducer_set_shard(void* h, int opt_kind, void* sgd_fn, void* adamw_fn, int n_buckets, void* const* master,
                           void* const* grad, void* const* s1, void* const* s2, void* const* lp,
                           const size_t* slice_counts, void* const* wbase, int wkind, int world) {
@@ -425,6 +459,7 @@ int dtp_reducer_set_shard(void* h, int opt_kind, void* sgd_fn, void* adamw_fn, i
   r->adamw = (dtp_adamw_fn)adamw_fn;
   r->wkind = wkind;
   r->opt_kind = opt_kind;
+  r->shard_world = world;
   return 0;
 }
 

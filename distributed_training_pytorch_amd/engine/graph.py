@@ -131,6 +131,10 @@ class GraphedTrainStep(object):
         self._seed_calls = self.rng.calls
         self.graph.replay()
         self.replays += 1
+        if self.raw.training and hasattr(self.model, "mark_buffers_dirty"):
+            # a replay bypasses DataParallel.forward: BatchNorm running statistics moved all the same,
+            # the lazy buffer broadcast (eval() / consolidate()) must not skip them
+            self.model.mark_buffers_dirty()
         # host-side bookkeeping that the eager path does per step
         if hasattr(self.optimizer, "_steps"):
             self.optimizer._steps += 1

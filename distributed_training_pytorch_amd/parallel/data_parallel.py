@@ -22,7 +22,7 @@ from .reducer import BucketedReducer, TorchPGTransport
 class DataParallel(nn.Module):
     def __init__(self, module, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
                  reduce_dtype=None, broadcast_buffers=True, transport=None, sync_init=True,
-                 shard_optimizer=None, bucket_align_elems=None):
+                 shard_optimizer=None, bucket_align_elems=None, bucket_optimizer=None):
         super().__init__()
         self.module = module
         self.broadcast_buffers = broadcast_buffers
@@ -34,12 +34,13 @@ class DataParallel(nn.Module):
             transport = self._pick_transport(params[0].device if params else torch.device("cpu"))
         kw = dict(bucket_cap_mb=bucket_cap_mb, first_bucket_mb=first_bucket_mb,
                   split_large_mb=split_large_mb, reduce_dtype=reduce_dtype, transport=transport)
-        if shard_optimizer is not None and not (arena is not None and arena.is_flat):
-            raise ValueError("shard_optimizer needs a model with a flat ParamArena")
+        if (shard_optimizer is not None or bucket_optimizer is not None) and not (arena is not None and arena.is_flat):
+            raise ValueError("shard_optimizer / bucket_optimizer need a model with a flat ParamArena")
         if arena is not None and arena.is_flat:
             self.reducer = BucketedReducer(arena.params, flat_grad=arena.flat_grad,
                                            flat_offsets=arena.offsets, shard_optimizer=shard_optimizer,
-                                           bucket_align_elems=bucket_align_elems, **kw)
+                                           bucket_align_elems=bucket_align_elems,
+                                           bucket_optimizer=bucket_optimizer, **kw)
             arena.reducer = self.reducer
             self.reducer.pre_ready = arena.sync_autograd_grad
         else:
@@ -101,9 +102,18 @@ class DataParallel(nn.Module):
         self._buffers_dirty = False
 
     def train(self, mode=True):
+        """NOTE: ``eval()`` / ``train(False)`` is a COLLECTIVE when the module has floating-point
+        buffers (BatchNorm running statistics) and world size > 1: every rank must call it (the
+        Trainer does).  ``module.eval()`` on the wrapped module switches one rank without
+        communication — at the price of that rank reading its own, unsynchronised statistics."""
         if not mode and self.broadcast_buffers and getattr(self, "reducer", None) is not None:
             self.sync_buffers()
         return super().train(mode)
+
+    def mark_buffers_dirty(self):
+        """Engines that run the training forward without going through :meth:`forward` (hipGraph
+        replays, engine/graph.py) report here that running statistics moved."""
+        self._buffers_dirty = True
 
     def forward(self, *args, **kwargs):
         if getattr(self.module, "param_arena", None) is not self._arena:

@@ -123,6 +123,16 @@ class NativeRcclTransport(object):
             raise RuntimeError("dtp_rccl_allreduce_async failed: %d" % rc)
         return True
 
+    def launch_sum(self, flat):
+        """In-place SUM (no averaging) — the exact fp32 hand-over of sharded mode (reducer.py)."""
+        if flat.dtype not in _KIND or not flat.is_cuda or not flat.is_contiguous():
+            raise ValueError("RCCL transport reduces contiguous CUDA f32/bf16 buffers")
+        rc = self.rt.dtp_rccl_allreduce_async(self.handle, ctypes.c_void_p(flat.data_ptr()), flat.numel(),
+                                              _KIND[flat.dtype], 0, self._stream())
+        if rc != 0:
+            raise RuntimeError("dtp_rccl_allreduce_async failed: %d" % rc)
+        return True
+
     def wait(self, handle, flat):
         if handle is None:
             return
@@ -345,11 +355,17 @@ def bring_up(device, want="auto"):
     """
     info = dict(requested=want, kind="torch", fell_back=False, reason=None)
     dev_index = device.index if device.index is not None else torch.cuda.current_device()
-    # Under the self-launcher (it exports DTP_RESTART_COUNT) a bring-up that does not finish is answered
-    # by a relaunch on the process-group transport, so the deadline is short.  Under any other launcher
-    # (torchrun: the driver's N > 1 bench runs) nobody relaunches — a late communicator beats a dead
-    # job, so wait almost as long as the process group itself would (DTP_PG_TIMEOUT_S, 600 s).
-    default_timeout = "180" if "DTP_RESTART_COUNT" in os.environ else "480"
+    # Deadline for step 2 (ncclCommInitRank + probe): 120 s under ANY launcher.  Step 1 has already
+    # built a communicator between exactly these processes (the process group's own, on the nccl
+    # backend), so a healthy second one comes up in seconds; 120 s is ~20x the slowest bring-up seen.
+    # The trade: under the self-launcher (it exports DTP_RESTART_COUNT) an expired deadline costs one
+    # relaunch on the process-group transport; under a foreign launcher (torchrun: the driver's N > 1
+    # runs) nobody relaunches and the job ends with exit code 75 — but it ends after 2 minutes with a
+    # message and a stack dump, inside the caller's own time budget (the driver allows a bench run
+    # 600 s), instead of sitting in ncclCommInitRank until that budget kills it without a word
+    # (round 2 waited 480 s here).  Callers that prefer the process-group transport outright set
+    # DTP_TRANSPORT=torch; a longer wait is DTP_NATIVE_INIT_TIMEOUT_S.
+    default_timeout = "120"
     timeout_s = float(os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", default_timeout))
     ok, payload, n, err = 1.0, b"", 0, None
     try:

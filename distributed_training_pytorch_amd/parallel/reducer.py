@@ -24,6 +24,11 @@ This module re-implements that contract, transport-agnostic:
     optimizer pass shrinks to 1/world per GPU and runs per bucket on the communication stream while
     backward is still producing the later buckets; bucket boundaries are snapped to multiples of
     ``world * 64`` elements so every bucket splits evenly.
+  * bucket-optimizer mode (``bucket_optimizer=``, the Trainer's default at world > 1): all-reduce per
+    bucket as before, but the fused optimizer updates each bucket's range right behind its
+    collective (native transport: on the communication stream, under the rest of backward) instead
+    of as one 134 M-element pass after the last bucket; ``optimizer.step()`` then only closes the
+    pass.  Same arithmetic per element as the replicated step — bit-identical parameters.
   * ``no_sync()`` gives gradient accumulation (skip all-reduce on non-boundary micro-steps,
     SURVEY.md §5.7); the averaging divide is folded into the collective (``AVG`` on RCCL) or
     one fused scale per bucket.
@@ -138,6 +143,15 @@ class TorchPGTransport(object):
             return ("host", (dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), host))
         return ("sum", dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def launch_sum(self, flat):
+        """Plain sum (no averaging) of a small buffer: the exact fp32 hand-over of sharded mode."""
+        if self.world == 1:
+            return None
+        if flat.is_cuda and self.backend != "nccl" and _GLOO_STAGE_HOST:
+            host = flat.to("cpu")
+            return ("ag_host", (dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), host))
+        return ("plain", dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
     def wait(self, handle, flat):
         if handle is None:
             return
@@ -201,7 +215,8 @@ class TorchPGTransport(object):
 class BucketedReducer(object):
     def __init__(self, params, bucket_cap_mb=None, first_bucket_mb=None, split_large_mb=None,
                  reduce_dtype=None, transport=None, flat_grad=None, flat_offsets=None,
-                 grad_dtype=None, shard_optimizer=None, bucket_align_elems=None, tail_bucket_mb=None):
+                 grad_dtype=None, shard_optimizer=None, bucket_align_elems=None, tail_bucket_mb=None,
+                 bucket_optimizer=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("BucketedReducer needs at least one trainable parameter")
@@ -248,26 +263,35 @@ class BucketedReducer(object):
         self.buckets = []
         self._param_buckets = {}
         self.sharded = False
+        self.fused_update = False    # an optimizer runs inside the reducer (sharded or per-bucket replicated)
         self.opt = None
-        if shard_optimizer is not None:
-            if flat_grad is None or getattr(shard_optimizer, "arena", None) is None \
-                    or shard_optimizer.arena.flat_grad is not flat_grad:
-                raise ValueError("shard_optimizer needs a fused flat-arena optimizer of the same model")
-            if reduce_dtype is not None and reduce_dtype != flat_grad.dtype:
+        if shard_optimizer is not None and bucket_optimizer is not None:
+            raise ValueError("shard_optimizer and bucket_optimizer are alternatives")
+        in_reducer = shard_optimizer if shard_optimizer is not None else bucket_optimizer
+        if in_reducer is not None:
+            if flat_grad is None or getattr(in_reducer, "arena", None) is None \
+                    or in_reducer.arena.flat_grad is not flat_grad:
+                raise ValueError("shard_optimizer / bucket_optimizer need a fused flat-arena optimizer of the same model")
+            if shard_optimizer is not None and reduce_dtype is not None and reduce_dtype != flat_grad.dtype:
                 raise ValueError("sharded mode reduces the gradient arena in place (no reduce_dtype)")
-            self.sharded = self.world > 1
-            self.opt = shard_optimizer
+            self.sharded = shard_optimizer is not None and self.world > 1
+            # (DTP_BUCKET_OPT_FORCE=1: also at world size 1 — one-GPU tests of the per-bucket path,
+            # incl. the C++ scheduler's optimizer launches on the communication stream)
+            self.fused_update = self.world > 1 or (bucket_optimizer is not None
+                                                   and os.environ.get("DTP_BUCKET_OPT_FORCE") == "1")
+            self.opt = in_reducer
         if flat_grad is not None:
             # arena mode: params' grads already are views of flat_grad at flat_offsets[i]; a bucket is
             # a contiguous element range [lo, hi) of the arena
             assert flat_offsets is not None and len(flat_offsets) == len(self.params)
             cuts = sorted(set(min(flat_offsets[i] + s for i, s, e in ranges) for ranges in plan))
             end = max(flat_offsets[i] + numels[i] for i in range(len(numels)))
-            if self.sharded or bucket_align_elems:
+            if self.sharded or bucket_align_elems or self.fused_update:
                 # every bucket must split evenly over the ranks into 64-element-aligned slices:
                 # snap the interior cuts down, extend the end into the arena's zero tail padding
-                # (bucket_align_elems: the same plan without sharding, for A/B and parity tests)
-                q = self.world * 64 if self.sharded else int(bucket_align_elems)
+                # (bucket_align_elems: the same plan without sharding, for A/B and parity tests;
+                # per-bucket replicated optimizer: the fused kernels update whole 64-element groups)
+                q = self.world * 64 if self.sharded else int(bucket_align_elems or 64)
                 cuts = sorted(set((c // q) * q for c in cuts))
                 end = (end + q - 1) // q * q
                 if end > flat_grad.numel():
@@ -298,10 +322,13 @@ class BucketedReducer(object):
                 self._add_bucket(_Bucket(bi, entries, flat))
             self._owns_grads = True
             self._point_grads()
-        if self.sharded:
+        if self.fused_update:
             self.opt._sharded_by = self
-            self._rank = comm.rank()
+            self._rank = comm.rank() if self.sharded else 0
             self._pass = None           # per-pass constants from the optimizer (first step flag / step number)
+            self._f32_sync = None       # sharded mode on GPUs: exact hand-over of the parameters kernels read in f32
+            if self.sharded:
+                self._build_f32_sync()
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_ready))
         if (flat_grad is not None and hasattr(self.transport, "make_scheduler")
@@ -309,7 +336,7 @@ class BucketedReducer(object):
             self._param_index = {id(p): i for i, p in enumerate(self.params)}
             lists = [[b.index for b in self._param_buckets[id(p)]] for p in self.params]
             self._core = self.transport.make_scheduler([b.flat for b in self.buckets], lists,
-                                                       shard=self._native_shard_spec() if self.sharded else None)
+                                                       shard=self._native_shard_spec() if self.fused_update else None)
             self._total_bytes = sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
     @property
@@ -351,9 +378,48 @@ class BucketedReducer(object):
 
     # ------------------------------------------------------------------ sharded mode helpers
     def my_slice(self, b):
-        """Arena element range of bucket ``b`` this rank owns (updates and contributes)."""
+        """Arena element range of bucket ``b`` this rank updates: its 1/world slice in sharded mode,
+        the whole bucket in the replicated per-bucket mode."""
+        if not self.sharded:
+            return b.lo, b.hi
         S = (b.hi - b.lo) // self.world
         return b.lo + self._rank * S, b.lo + (self._rank + 1) * S
+
+    def _build_f32_sync(self):
+        """Sharded mode on GPUs all-gathers only the bf16 working copy; the fp32 master of the slices a
+        rank does not own goes stale until :meth:`consolidate`.  That is fine for the matrices (the
+        kernels read their bf16 copy) but NOT for what the kernels read in fp32 from the master: every
+        bias and the BatchNorm affine pairs (ops/layers.py) — with stale values each rank would run its
+        forward on a slightly different model.  Those parameters are tiny (VGG16: 12.4 k floats), so
+        after a pass each rank contributes the elements it owns, zeros elsewhere, to ONE small fp32
+        all-reduce(sum): x + 0 + ... + 0 is exact, every rank ends with the owners' bits."""
+        a = self.opt.arena
+        if a.flat_lp is None:
+            return                      # CPU: the all-gather already moves the fp32 master itself
+        idx = [torch.arange(a.offsets[i], a.offsets[i] + p.numel()) for i, p in enumerate(a.params) if p.dim() <= 1]
+        if not idx:
+            return
+        idx = torch.cat(idx)
+        owned = torch.zeros(idx.numel(), dtype=torch.bool)
+        for b in self.buckets:
+            lo, hi = self.my_slice(b)
+            owned |= (idx >= lo) & (idx < hi)
+        dev = a.flat_master.device
+        n = (idx.numel() + 63) // 64 * 64
+        self._f32_sync = dict(idx=idx.to(dev), owned=owned.to(dev).to(torch.float32),
+                              buf=torch.zeros(n, dtype=torch.float32, device=dev), n=idx.numel())
+
+    def _sync_f32_read_params(self):
+        fs = self._f32_sync
+        if fs is None:
+            return
+        a = self.opt.arena
+        buf, n = fs["buf"], fs["n"]
+        torch.index_select(a.flat_master, 0, fs["idx"], out=buf[:n])
+        buf[:n].mul_(fs["owned"])
+        tr = self.transport
+        tr.wait(tr.launch_sum(buf), buf)
+        a.flat_master.index_copy_(0, fs["idx"], buf[:n])
 
     def _weights_flat(self):
         """What the all-gather distributes: the bf16 working copy on GPUs (half the bytes; the fp32
@@ -364,7 +430,8 @@ class BucketedReducer(object):
     def _native_shard_spec(self):
         a = self.opt.arena
         return dict(optimizer=self.opt, arena=a, weights=self._weights_flat(),
-                    ranges=[(b.lo, b.hi) for b in self.buckets], rank=self._rank, world=self.world)
+                    ranges=[(b.lo, b.hi) for b in self.buckets], rank=self._rank,
+                    world=self.world if self.sharded else 1)      # 1: replicated per-bucket update
 
     def _begin_pass(self):
         if self._pass is None:
@@ -413,7 +480,7 @@ class BucketedReducer(object):
         if self.pre_ready is not None:
             self.pre_ready(p)
         if self._core is not None:       # counting + launch in C++ (one call)
-            if self.sharded and self.require_sync:
+            if self.fused_update and self.require_sync:
                 self._begin_pass()       # the C++ side needs this pass's optimizer constants first
             self.stats["launched"] += self._core.mark_ready(self._param_index[id(p)])
             return
@@ -448,8 +515,9 @@ class BucketedReducer(object):
             self._launch_traced(b, buf)
 
     def _launch_traced(self, b, buf):
-        if self.sharded:
+        if self.fused_update:
             self._begin_pass()
+        if self.sharded:
             b.work = self.transport.reduce_scatter(buf)
             self.stats["launched"] += 1
             self.stats["bytes"] += buf.numel() * buf.element_size()
@@ -470,16 +538,18 @@ class BucketedReducer(object):
                     and not torch.cuda.is_current_stream_capturing():
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            if self.sharded and self.require_sync:
+            if self.fused_update and self.require_sync:
                 self._begin_pass()
             self.stats["launched"] += self._core.finalize()
             if self.require_sync:
+                if self.sharded:
+                    self._sync_f32_read_params()
                 if ev0 is not None:
                     ev1.record()
                     self._exposed_pairs.append((ev0, ev1))
                 self.stats["finalized"] += 1
                 self.stats["bytes"] += self._total_bytes
-                if self.sharded:
+                if self.fused_update:
                     self.opt.step_closed_by_reducer()
                     self._pass = None
             self._ready_ids.clear()
@@ -506,8 +576,10 @@ class BucketedReducer(object):
                     gathers.append((self.transport.all_gather(seg), seg))
                 for h, seg in gathers:
                     self.transport.wait(h, seg)
+                self._sync_f32_read_params()
                 self.opt.step_closed_by_reducer()
                 self._pass = None
+            kw = self._begin_pass() if (self.fused_update and not self.sharded) else None
             for b in (() if self.sharded else self.buckets):
                 buf = b.comm_buf if b.comm_buf is not None else b.flat
                 self.transport.wait(b.work, buf)
@@ -516,6 +588,11 @@ class BucketedReducer(object):
                     b.comm_buf = None
                 if self._owns_grads:
                     self._scatter_split_params(b)
+                if kw is not None:       # replicated per-bucket update, in launch order
+                    self.opt.update_range(b.lo, b.hi, **kw)
+            if kw is not None:
+                self.opt.step_closed_by_reducer()
+                self._pass = None
             if ev0 is not None:
                 ev1.record()
                 self._exposed_pairs.append((ev0, ev1))
@@ -557,8 +634,9 @@ class BucketedReducer(object):
         the C++ scheduler on plain HIP streams / events — an event record on the capturing compute
         stream plus a wait on the communication stream forks that stream into the capture, the
         hand-back joins it — and RCCL records its collective kernels like any other launch.  The
-        sharded-optimizer mode keeps per-pass host state (step constants) and is not captured."""
-        return self._core is not None and not self.sharded
+        optimizer-in-reducer modes (sharded, per-bucket replicated) keep per-pass host state (step
+        constants handed to the C++ scheduler) and are not captured."""
+        return self._core is not None and not self.fused_update
 
     def finalize_now(self):
         """Explicit finalize for engines that do not run through ``torch.autograd``."""

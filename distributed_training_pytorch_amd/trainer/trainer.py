@@ -76,6 +76,7 @@ class Trainer(object):
                  use_hip_graph=False,
                  cache_dataset_on_device=False,
                  shard_optimizer=False,
+                 bucket_optimizer=True,
                  step_timing=None):
         # T1 logging shim (plain method, keyword-friendly; reference :26)
         self.logger = logger
@@ -156,8 +157,19 @@ class Trainer(object):
         # gradient synchronisation (replaces DDP; broadcasts rank 0's state, X2)
         # shard_optimizer: reduce-scatter + per-bucket optimizer on 1/world of the arena + all-gather
         # (parallel/reducer.py) instead of all-reduce + replicated optimizer
+        # bucket_optimizer (default): all-reduce as usual, but the fused optimizer updates each bucket's
+        # range right behind its collective (native transport: on the communication stream) — the
+        # 0.5 ms pass over 134 M parameters no longer runs un-overlapped after the last bucket.  Needs
+        # a fused flat-arena optimizer; a captured hipGraph step keeps the replicated step (the
+        # per-pass optimizer constants live on the host).
+        sharded = bool(shard_optimizer) and self.world_size > 1
+        per_bucket = (bool(bucket_optimizer) and not sharded and self.world_size > 1 and not use_hip_graph
+                      and hasattr(self.optimizer, "update_range")
+                      and getattr(self.optimizer, "arena", None) is getattr(self.model, "param_arena", None)
+                      and getattr(self.model, "param_arena", None) is not None)
         self.model = DataParallel(self.model, bucket_cap_mb=bucket_cap_mb, reduce_dtype=reduce_dtype,
-                                  shard_optimizer=self.optimizer if (shard_optimizer and self.world_size > 1) else None)
+                                  shard_optimizer=self.optimizer if sharded else None,
+                                  bucket_optimizer=self.optimizer if per_bucket else None)
         if self.use_hip_graph and self.device.type == "cuda" and self.grad_accum_steps == 1:
             from ..engine.graph import GraphedTrainStep
             self.graphed_step = GraphedTrainStep(self.model, self.criterion, self.optimizer)

@@ -49,6 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--hip-graph", action="store_true", help="capture the train step into one hipGraph (data-parallel: native RCCL transport only)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + per-bucket sharded optimizer + all-gather instead of all-reduce")
+    ap.add_argument("--no-bucket-optimizer", action="store_true",
+                    help="world > 1: one optimizer pass after the last gradient bucket instead of per bucket "
+                         "behind its all-reduce (the default)")
+    ap.add_argument("--seed", type=int, default=0, help="seeds torch (init, CPU dropout) and keys the GPU dropout masks")
     ap.add_argument("--nproc", type=int, default=0,
                     help="self-launch this many local ranks (one per GPU) without torchrun; 0: run in this process")
     ap.add_argument("--max-restarts", type=int, default=0,
@@ -71,10 +75,24 @@ def pick_snapshot(args):
     shell before the first launch)."""
     if args.snapshot or args.no_auto_resume:
         return args.snapshot
-    last = os.path.join(args.save_folder, "weights", "last.pth")
-    if restart_count() > 0 and os.path.isfile(last):
+    if restart_count() == 0:
+        return None
+    wdir = os.path.join(args.save_folder, "weights")
+    last = os.path.join(wdir, "last.pth")
+    if os.path.isfile(last):
         return last
-    return None
+    # runs without validation write checkpoint_epoch_N.pth instead of last.pth (reference
+    # trainer/trainer.py:163-167): resume from the newest of those
+    import re
+    best_n, best_path = -1, None
+    for name in (os.listdir(wdir) if os.path.isdir(wdir) else []):
+        m = re.fullmatch(r"checkpoint_epoch_(\d+)\.pth", name)
+        if m and int(m.group(1)) > best_n:
+            best_n, best_path = int(m.group(1)), os.path.join(wdir, name)
+    if best_path is None:
+        print("WARNING: restarted job (restart %d) found no snapshot under %s - training starts from epoch 0"
+              % (restart_count(), wdir), flush=True)
+    return best_path
 
 
 if __name__ == "__main__":
@@ -113,6 +131,7 @@ if __name__ == "__main__":
                              max_steps_per_epoch=args.steps,
                              progress=not args.no_progress, use_hip_graph=args.hip_graph, cache_dataset_on_device=args.device_cache,
                              shard_optimizer=args.shard_optimizer, ring_loader=args.ring_loader,
+                             bucket_optimizer=not args.no_bucket_optimizer, seed=args.seed,
                              metrics_file="%s/metrics.jsonl" % args.save_folder)
 
     trainer.train()

@@ -203,7 +203,7 @@ def scenario_sharded(out):
     X = torch.randn(6, 8 * world, 16, generator=g)
     Y = torch.randint(0, 5, (6, 8 * world), generator=g)
 
-    def run(opt_cls, sharded, **okw):
+    def run(opt_cls, sharded, per_bucket=False, align=None, **okw):
         torch.manual_seed(4321)
         net = Net()
         opt = opt_cls(net, **okw)
@@ -212,8 +212,10 @@ def scenario_sharded(out):
         # only equal messages give equal bits at world 4
         dp = DataParallel(net, bucket_cap_mb=0.02, first_bucket_mb=0.004,
                           shard_optimizer=opt if sharded else None,
-                          bucket_align_elems=None if sharded else world * 64)
+                          bucket_optimizer=opt if per_bucket else None,
+                          bucket_align_elems=None if (sharded or per_bucket) else (align or world * 64))
         assert dp.reducer.sharded == sharded
+        assert dp.reducer.fused_update == (sharded or per_bucket)
         assert len(dp.reducer.buckets) >= 3, dp.reducer.bucket_summary()
         if sharded:
             for b in dp.reducer.buckets:
@@ -249,6 +251,101 @@ def scenario_sharded(out):
             raise AssertionError("sharded step() without a backward pass must raise")
         except RuntimeError:
             pass
+        # the default data-parallel path: all-reduce per bucket + the optimizer on each bucket's range
+        # right behind it (replicated) == all-reduce + one optimizer pass, bit for bit
+        ref_w, ref_s, _ = run(opt_cls, False, align=64, **okw)
+        pb_w, pb_s, dpb = run(opt_cls, False, per_bucket=True, **okw)
+        assert not dpb.reducer.sharded and len(dpb.reducer.buckets) >= 3
+        assert torch.equal(ref_w, pb_w), "%s: per-bucket optimizer parameters differ (max %g)" % (
+            opt_cls.__name__, float((ref_w - pb_w).abs().max()))
+        assert torch.equal(ref_s, pb_s), "%s: per-bucket optimizer state differs" % opt_cls.__name__
+        assert _allclose_across_ranks(pb_w) and _allclose_across_ranks(pb_s)
+
+
+def scenario_gpu_modes(out):
+    """VGG16-BN (biases + BatchNorm affine pairs + running statistics, dropout 0.3) on GPUs, 5 steps,
+    in every gradient-synchronisation mode: all-reduce + replicated step, per-bucket optimizer (the
+    default), sharded optimizer, and — on the native RCCL transport — the hipGraph-captured step.
+    Asserts: parameters (incl. the fp32 biases / BN affine values the kernels read from the master)
+    agree across ranks after EVERY step in every mode; buffers agree after eval(); per-bucket ==
+    all-reduce bit for bit; sharded and hipGraph land on the all-reduce result.
+    One-GPU box: ranks share cuda:0 over gloo (Python reducer path); DTP_TEST_MULTI_GPU=1: one GPU
+    per rank, RCCL, native transport (C++ scheduler)."""
+    from distributed_training_pytorch_amd.engine.graph import GraphedTrainStep
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+    rank, world = dist.get_rank(), dist.get_world_size()
+    multi = os.environ.get("DTP_TEST_MULTI_GPU") == "1"
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if multi else 0)
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(5, 8 * world, 3, 32, 32, generator=g)
+    Y = torch.randint(0, 3, (5, 8 * world), generator=g)
+
+    def run(mode):
+        torch.manual_seed(55)
+        net = VGG16(3, 3, True, batch_norm=True, dropout=0.3, grad_dtype=torch.bfloat16).to(dev).train()
+        net.dropout_rng.seed = 77
+        opt = FusedSGD(net, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        crit = SoftmaxCrossEntropy()
+        dp = DataParallel(net, shard_optimizer=opt if mode == "sharded" else None,
+                          bucket_optimizer=opt if mode == "bucket" else None,
+                          bucket_align_elems=64 if mode in ("allreduce", "graph") else None,
+                          bucket_cap_mb=4.0, first_bucket_mb=1.0)
+        if multi:
+            assert type(dp.reducer.transport).__name__ == "NativeRcclTransport", dp.reducer.transport.info
+        a = net.param_arena
+        small = torch.cat([torch.arange(a.offsets[i], a.offsets[i] + p.numel()) for i, p in enumerate(a.params)
+                           if p.dim() <= 1]).to(dev)
+        graphed = GraphedTrainStep(dp, crit, opt, warmup=1) if mode == "graph" else None
+        if graphed is not None:
+            assert graphed.enabled and graphed.distributed
+        losses = []
+        for it in range(5):
+            xs, ys = X[it, rank::world].to(dev), Y[it, rank::world].to(dev)
+            if graphed is not None:
+                loss = graphed(xs, ys)
+            else:
+                opt.zero_grad()
+                loss = crit(dp(xs), ys)
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            losses.append(float(loss.detach()))
+            # what the NEXT forward reads: bf16 working copy everywhere, fp32 master for biases / BN affine
+            assert _allclose_across_ranks(a.flat_lp.float().cpu()), "%s step %d: working weights diverged" % (mode, it)
+            assert _allclose_across_ranks(a.flat_master[small].cpu()), \
+                "%s step %d: fp32-read parameters (biases / BatchNorm affine) differ across ranks" % (mode, it)
+        if graphed is not None:
+            assert graphed.captures == 1 and graphed.replays == 4
+        dp.consolidate()
+        dp.eval()                                              # collective: running statistics follow rank 0
+        torch.cuda.synchronize()
+        w = a.flat_master[:a.total].detach().cpu().clone()
+        bufs = torch.cat([b.detach().float().reshape(-1).cpu() for b in net.buffers() if b.is_floating_point()])
+        assert _allclose_across_ranks(w), "%s: parameters diverged across ranks" % mode
+        assert _allclose_across_ranks(bufs), "%s: buffers differ across ranks after eval()" % mode
+        assert all(l == l for l in losses), (mode, losses)
+        dp.close()
+        return w, losses
+
+    ref_w, ref_l = run("allreduce")
+    pb_w, pb_l = run("bucket")
+    assert torch.equal(ref_w, pb_w) and ref_l == pb_l, "per-bucket optimizer != all-reduce + replicated step (max %g)" % (
+        float((ref_w - pb_w).abs().max()))
+    sh_w, sh_l = run("sharded")
+    # different bucket cuts -> a different summation order inside the collective at world > 2; bf16 gradients
+    scale = float(ref_w.abs().max())
+    assert float((ref_w - sh_w).abs().max()) <= 2e-3 * scale, "sharded drifted from all-reduce: %g" % (
+        float((ref_w - sh_w).abs().max()))
+    if world == 2 and not multi:
+        assert torch.equal(ref_w, sh_w), "world 2 over gloo: sharded must equal all-reduce bit for bit"
+    if multi:
+        gr_w, gr_l = run("graph")
+        assert torch.equal(ref_w, gr_w) and ref_l == gr_l, "hipGraph data-parallel step != eager (max %g)" % (
+            float((ref_w - gr_w).abs().max()))
+    open(os.path.join(out, "modes.%d" % rank), "w").write(json.dumps(dict(allreduce=ref_l, bucket=pb_l, sharded=sh_l)))
 
 
 def scenario_small_val(out):
@@ -285,7 +382,8 @@ if __name__ == "__main__":
     penv.ddp_setup("nccl" if os.environ.get("DTP_TEST_MULTI_GPU") == "1" else "gloo",
                    timeout_s=float(os.environ.get("DTP_PG_TIMEOUT_S", "60")))
     {"reducer": scenario_reducer, "trainer": scenario_trainer, "fault": scenario_fault,
-     "gpu_shared": scenario_gpu_shared, "sharded": scenario_sharded, "small_val": scenario_small_val}[scenario](out)
+     "gpu_shared": scenario_gpu_shared, "sharded": scenario_sharded, "small_val": scenario_small_val,
+     "gpu_modes": scenario_gpu_modes}[scenario](out)
     comm.barrier()
     open(os.path.join(out, "ok.%d" % dist.get_rank()), "w").write("ok")
     penv.destroy_process()

@@ -9,8 +9,10 @@
 
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
-struct MockStream { int id; bool non_blocking; int priority; };
-struct MockEvent { int id; int records; const MockStream* last_stream; bool destroyed; };
+constexpr hipError_t hipErrorNotReady = 600;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+struct MockStream { int id; bool non_blocking; int priority; bool capturing = false; };
+struct MockEvent { int id; int records; const MockStream* last_stream; bool destroyed; bool pending = false; };
 typedef MockStream* hipStream_t;
 typedef MockEvent* hipEvent_t;
 constexpr unsigned hipEventDisableTiming = 2;
@@ -20,6 +22,7 @@ struct MockLog {
   std::vector<std::string> calls;
   int events_created = 0, events_destroyed = 0, streams_created = 0, streams_destroyed = 0;
   int fail_event_create_after = -1;     // inject hipEventCreate failures
+  bool keep_events_pending = false;     // recorded events stay "not ready" until mock_complete_all_events()
 };
 MockLog& mock_log();
 
@@ -31,3 +34,5 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st);

@@ -15,9 +15,10 @@
 static MockLog g_log;
 MockLog& mock_log() { return g_log; }
 static void logc(const std::string& s) { g_log.calls.push_back(s); }
+static std::vector<MockEvent*> g_live_events;
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags) {   // default priority: by construction
-  *s = new MockStream{100 + g_log.streams_created++, (flags & hipStreamNonBlocking) != 0, 0};
+  *s = new MockStream{100 + g_log.streams_created++, (flags & hipStreamNonBlocking) != 0, 0, false};
   return hipSuccess;
 }
 hipError_t hipStreamDestroy(hipStream_t s) { ++g_log.streams_destroyed; delete s; return hipSuccess; }
@@ -30,16 +31,31 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) {
   if (g_log.fail_event_create_after >= 0 && g_log.events_created >= g_log.fail_event_create_after) return 2;
   *e = new MockEvent{g_log.events_created++, 0, nullptr, false};
+  g_live_events.push_back(*e);
+  return hipSuccess;
+}
+static void mock_complete_all_events() { for (MockEvent* e : g_live_events) e->pending = false; }
+hipError_t hipEventQuery(hipEvent_t e) { assert(e && !e->destroyed); return e->pending ? hipErrorNotReady : hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st) {
+  *st = (s && s->capturing) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
   return hipSuccess;
 }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
   assert(e && !e->destroyed);
+  assert(!e->pending && "re-recording an event whose previous work has not completed");
+  e->pending = g_log.keep_events_pending;
   ++e->records;
   e->last_stream = s;
   logc("record:" + std::to_string(s ? s->id : 0));
   return hipSuccess;
 }
-hipError_t hipEventDestroy(hipEvent_t e) { ++g_log.events_destroyed; e->destroyed = true; delete e; return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) {
+  ++g_log.events_destroyed;
+  for (auto& p : g_live_events) if (p == e) { p = g_live_events.back(); g_live_events.pop_back(); break; }
+  e->destroyed = true;
+  delete e;
+  return hipSuccess;
+}
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { std::memset(id, 7, sizeof(*id)); return ncclSuccess; }
 static int g_comms = 0;
 ncclResult_t ncclCommInitRank(ncclComm_t* c, int world, ncclUniqueId id, int rank) {
@@ -87,6 +103,7 @@ int dtp_rccl_broadcast(void* h, void* buf, size_t count, int dtype_kind, int roo
 int dtp_rccl_sync(void* h);
 int dtp_rccl_stats(void* h, unsigned long long* launched, unsigned long long* bytes);
 int dtp_rccl_destroy(void* h);
+int dtp_rccl_event_count(void* h);
 void* dtp_reducer_create(void* transport, int n_buckets, void* const* ptrs, const size_t* counts,
                          const int* dtype_kinds, int n_params, const int* pb_offsets, const int* pb_indices);
 int dtp_reducer_mark_ready(void* h, int param, hipStream_t producer_stream);
@@ -166,6 +183,81 @@ static void test_sharded_scheduler(void* transport, MockStream* compute) {
   assert(dtp_reducer_destroy(r) == 0);
 }
 
+// replicated optimizer-in-scheduler mode (the default data-parallel path): per bucket all-reduce ->
+// fused optimizer over the WHOLE bucket on the comm stream, no all-gather; one consumer wait per pass
+static void test_replicated_bucket_optimizer(void* transport, MockStream* compute) {
+  static float master[256], mom[256];
+  static unsigned short grad[256], lp[256];
+  void* ptrs[2] = {grad + 128, grad};
+  size_t counts[2] = {128, 128};
+  int kinds[2] = {1, 1};
+  int offs[3] = {0, 1, 2};
+  int idx[2] = {1, 0};
+  void* r = dtp_reducer_create(transport, 2, ptrs, counts, kinds, 2, offs, idx);
+  assert(r);
+  void* m_[2] = {master + 128, master};
+  void* g_[2] = {grad + 128, grad};
+  void* s1_[2] = {mom + 128, mom};
+  void* lp_[2] = {lp + 128, lp};
+  size_t sc[2] = {128, 128};
+  assert(dtp_reducer_set_shard(r, 1, (void*)fake_sgd, nullptr, 2, m_, g_, s1_, nullptr, lp_, sc, lp_, 1, /*world=*/1) == 0);
+  for (int pass = 0; pass < 2; ++pass) {
+    const float hyper[4] = {0.5f, 0.9f, 0.0f, 1e-4f};
+    const int iargs[2] = {0, pass == 0};
+    assert(dtp_reducer_begin_pass(r, hyper, 4, iargs, 2) == 0);
+    g_log.calls.clear();
+    assert(dtp_reducer_mark_ready(r, 1, compute) == 1);
+    assert(g_log.calls.size() == 4);
+    assert(g_log.calls[0] == "record:1" && g_log.calls[1] == "wait:100:on:1");
+    assert(g_log.calls[2].rfind("allreduce:100:128:", 0) == 0);
+    assert(g_log.calls[3] == std::string("sgd:100:128:1:1:0") + (pass == 0 ? "1" : "0"));
+    assert(dtp_reducer_finalize(r, compute) == 1);
+    assert(count_calls("allreduce") == 2 && count_calls("sgd") == 2 && count_calls("allgather") == 0 &&
+           count_calls("reducescatter") == 0);
+    assert(g_log.calls.back() == "wait:1:on:100");
+  }
+  assert(dtp_reducer_destroy(r) == 0);
+}
+
+// 40 buckets per pass whose events stay pending for the whole pass (nothing completes until the
+// consumer has synchronised): the pool must GROW past its nominal ring size instead of re-recording
+// a live event (the mock's hipEventRecord asserts that), and shrink its appetite again afterwards;
+// events recorded while the producer stream is being captured are never handed out again
+static void test_event_pool_never_rerecords_live_events(void* transport, MockStream* compute) {
+  constexpr int NB = 40;
+  static float g[NB][16];
+  void* ptrs[NB]; size_t counts[NB]; int kinds[NB]; int offs[NB + 1]; int idx[NB];
+  for (int b = 0; b < NB; ++b) { ptrs[b] = g[b]; counts[b] = 16; kinds[b] = 0; offs[b] = b; idx[b] = b; }
+  offs[NB] = NB;
+  void* r = dtp_reducer_create(transport, NB, ptrs, counts, kinds, NB, offs, idx);
+  assert(r);
+  const int before = dtp_rccl_event_count(transport);
+  g_log.keep_events_pending = true;
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int p = 0; p < NB; ++p) assert(dtp_reducer_mark_ready(r, p, compute) == 1);
+    assert(dtp_reducer_finalize(r, compute) == 0);
+  }
+  const int grown = dtp_rccl_event_count(transport);
+  assert(grown >= 3 * (NB + 1) && grown > before && "pending events must not be reused");
+  mock_complete_all_events();                 // the device caught up
+  g_log.keep_events_pending = false;
+  for (int pass = 0; pass < 50; ++pass) {
+    for (int p = 0; p < NB; ++p) assert(dtp_reducer_mark_ready(r, p, compute) == 1);
+    assert(dtp_reducer_finalize(r, compute) == 0);
+  }
+  assert(dtp_rccl_event_count(transport) == grown && "completed events are reused, the pool stops growing");
+  // capture: every event of a captured pass is fresh and stays out of the reusable pool
+  compute->capturing = true;
+  for (int p = 0; p < NB; ++p) assert(dtp_reducer_mark_ready(r, p, compute) == 1);
+  assert(dtp_reducer_finalize(r, compute) == 0);
+  compute->capturing = false;
+  assert(dtp_rccl_event_count(transport) == grown + NB + 1);
+  for (int p = 0; p < NB; ++p) assert(dtp_reducer_mark_ready(r, p, compute) == 1);
+  assert(dtp_reducer_finalize(r, compute) == 0);
+  assert(dtp_rccl_event_count(transport) == grown + NB + 1);
+  assert(dtp_reducer_destroy(r) == 0);
+}
+
 // bucket scheduler: params 0,1 -> bucket 0; param 2 -> buckets 1 and 2 (split); param 3 -> bucket 2
 static void test_scheduler(void* transport, MockStream* compute) {
   float g[4][32];
@@ -221,7 +313,7 @@ int main() {
   void* t = dtp_rccl_create(id, 1, 4, 0);
   assert(t && g_comms == 1 && g_log.streams_created == 1);
 
-  MockStream compute{1, false, 0};
+  MockStream compute{1, false, 0, false};
   float buf[64];
   assert(dtp_rccl_allreduce_async(nullptr, buf, 64, 0, 1, &compute) == -2);
   assert(dtp_rccl_allreduce_async(t, nullptr, 64, 0, 1, &compute) == -2);
@@ -255,6 +347,8 @@ int main() {
 
   test_scheduler(t, &compute);
   test_sharded_scheduler(t, &compute);
+  test_replicated_bucket_optimizer(t, &compute);
+  test_event_pool_never_rerecords_live_events(t, &compute);
   g_log.calls.clear();
   assert(dtp_rccl_broadcast(t, buf, 64, 0, 0, &compute) == 0);
   assert(g_log.calls.size() == 5 && g_log.calls[2] == "broadcast:100:64:0" && g_log.calls[4] == "wait:1:on:100");

@@ -19,7 +19,7 @@ _port = [29900 + (os.getpid() % 50)]
 
 
 def _env(**kw):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DTP_PG_TIMEOUT_S="300", DTP_NATIVE_INIT_TIMEOUT_S="240")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DTP_PG_TIMEOUT_S="300")
     env.update(kw)
     return env
 
@@ -41,7 +41,32 @@ def test_fused_model_data_parallel_over_native_rccl(tmp_path, world):
     assert all(l[-1] < l[0] for l in losses), losses
 
 
-@pytest.mark.parametrize("extra", [[], ["--shard-optimizer"], ["--grad-accum", "2"]])
+@pytest.mark.parametrize("world", WORLDS or [2])
+def test_every_sync_mode_agrees_across_ranks_and_with_allreduce(tmp_path, world):
+    """VGG16-BN through all-reduce, per-bucket optimizer, sharded optimizer and the hipGraph-captured
+    data-parallel step on the native transport (tests/dist_worker.py gpu_modes): cross-rank equality of
+    everything the kernels read after every step, per-bucket and hipGraph == all-reduce bit for bit."""
+    _port[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(_port[0]), WORKER, "gpu_modes", str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(DTP_TEST_MULTI_GPU="1", DTP_TRANSPORT="native"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-6000:]
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == sorted("ok.%d" % i for i in range(world))
+
+
+def test_main_hip_graph_data_parallel_two_gpus(tmp_path):
+    """`main.py --nproc 2 --hip-graph`: the Trainer's captured step INCLUDING the RCCL collectives."""
+    cmd = [sys.executable, os.path.join(ROOT, "main.py"), "--nproc", "2", "--synthetic", "--synthetic-size", "256",
+           "--epochs", "2", "--batch-size", "32", "--image-size", "32", "--no-validate", "--no-progress", "--hip-graph",
+           "--save-folder", str(tmp_path / "runs")]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(DTP_TRANSPORT="native"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-6000:]
+    assert "Finished!" in r.stdout and os.path.exists(tmp_path / "runs" / "weights" / "checkpoint_epoch_2.pth")
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-bucket-optimizer"], ["--shard-optimizer"], ["--grad-accum", "2"]])
 def test_bench_self_launch_two_gpus_native_transport(extra):
     """`python bench.py --gpus 2` from a bare shell: the self-launcher starts one fresh worker per
     GPU; the JSON line must report both ranks, the native transport (no fall-back) and a passed
