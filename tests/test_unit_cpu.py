@@ -496,3 +496,27 @@ def test_snapshot_carries_rng_state_and_trainer_seeds_torch(tmp_path):
     assert torch.equal(torch.get_rng_state(), rs["torch_cpu"])
     tr3 = ExampleTrainer(max_epoch=1, seed=5, **dict(kw, save_folder=str(tmp_path / "runs3")))
     assert torch.equal(tr3.raw_model.param_arena.flat_master, w0), "same seed must give the same initial weights"
+
+
+def test_topk_hits_matches_sklearn_top_k_accuracy_score():
+    """eval.py's metric == the reference's (``sklearn.metrics.top_k_accuracy_score``, reference
+    eval.py:69-70) on random scores WITH ties (scores quantised to 4 levels), k = 1, 2, for 3 and 7
+    classes — including sklearn's tie order (higher class index first)."""
+    sk = pytest.importorskip("sklearn.metrics")
+    import numpy as np
+    import eval as ev
+    rng = np.random.RandomState(0)
+    for C in (3, 7):
+        for trial in range(20):
+            n = 64
+            scores = rng.randint(0, 4, size=(n, C)).astype(np.float32) / 3.0      # many exact ties
+            labels = rng.randint(0, C, size=n)
+            labels[:C] = np.arange(C)                                             # every class present
+            for k in (1, 2):
+                want = sk.top_k_accuracy_score(labels, scores, k=k, labels=np.arange(C), normalize=False)
+                got = ev.topk_hits(torch.from_numpy(scores), torch.from_numpy(labels), k)
+                assert got == int(want), (C, trial, k, got, want)
+    # all scores equal: only the top-k highest indices "hit"
+    z = torch.zeros(5, 4)
+    assert ev.topk_hits(z, torch.tensor([3, 3, 2, 1, 0]), 1) == 2
+    assert ev.topk_hits(z, torch.tensor([3, 3, 2, 1, 0]), 2) == 3
