@@ -65,6 +65,11 @@ def parse_args(argv=None):
     ap.add_argument("--fp8-classifier", action="store_true", help="linear1/linear2 GEMMs in OCP e4m3 (config 5)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + per-bucket sharded SGD + all-gather instead of all-reduce + replicated SGD")
+    ap.add_argument("--fresh-data", action="store_true",
+                    help="every warm-up and timed step sees a batch it has not seen before (n_distinct = warmup + "
+                         "steps device-resident batches) instead of cycling through 2: the net cannot memorise, "
+                         "so activation / gradient sparsity — which the power-limited matrix kernels are "
+                         "sensitive to — stays that of a freshly initialised net")
     ap.add_argument("--no-bucket-optimizer", action="store_true",
                     help="N > 1: run the fused SGD as one pass after the last gradient bucket instead of per "
                          "bucket behind its all-reduce (the default; parallel/reducer.py)")
@@ -155,9 +160,11 @@ def main(argv=None):
         data_desc = ("synthetic (uint8 NCHW batches in a pinned host ring, H2D copy on the copy stream inside the "
                      "timed region, normalisation fused into conv1; random-init weights)")
     else:
+        n_distinct = (args.warmup + args.steps) * args.grad_accum if args.fresh_data else 2
         data = DeviceBatchSource(micro, args.classes, args.image_size, args.image_size,
-                                 device=dev, n_distinct=2, seed=rank)
-        data_desc = "synthetic (device-resident f32 NCHW batches, random-init weights)"
+                                 device=dev, n_distinct=n_distinct, seed=rank)
+        data_desc = "synthetic (device-resident f32 NCHW batches, %s, random-init weights)" % (
+            "a fresh batch every step" if args.fresh_data else "2 distinct batches cycled")
 
     def step():
         opt.zero_grad()
@@ -195,11 +202,31 @@ def main(argv=None):
     exposed0 = dp.reducer.exposed_ms_total()
     wait0 = getattr(data, "wait_ms_total", lambda: 0.0)()
     starved0 = getattr(data, "starved_ms_total", lambda: 0.0)()
+    # HIP events around the first and the last five timed steps (recorded on the compute stream, read
+    # after the closing fence: no extra synchronisation): shows whether throughput drifts while the
+    # net memorises its batches (activation sparsity moves; the matrix kernels are power-limited)
+    marks = {}
+    edge = min(5, args.steps)
+
+    def mark(name):
+        if on_gpu:
+            marks[name] = torch.cuda.Event(enable_timing=True)
+            marks[name].record()
+
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == 0:
+            mark("first_begin")
+        if i == args.steps - edge:
+            mark("last_begin")
         loss = step()
+        if i == edge - 1:
+            mark("first_end")
+    mark("last_end")
     fence()
     dt = time.perf_counter() - t0
+    ms_first = marks["first_begin"].elapsed_time(marks["first_end"]) / edge if on_gpu and edge else None
+    ms_last = marks["last_begin"].elapsed_time(marks["last_end"]) / edge if on_gpu and edge else None
     exposed = (dp.reducer.exposed_ms_total() - exposed0) / max(1, args.steps)
     data_wait = (getattr(data, "wait_ms_total", lambda: 0.0)() - wait0) / max(1, args.steps)
     data_starved = (getattr(data, "starved_ms_total", lambda: 0.0)() - starved0) / max(1, args.steps)
@@ -219,6 +246,17 @@ def main(argv=None):
     if on_gpu:
         torch.cuda.synchronize()
     transport_ok = bool(((probe - (world + 1) / 2.0).abs() < 1e-5).all())
+    # after all those steps every rank must hold the same model: checksum of the fp32 master weights,
+    # min and max over ranks (a diverged replica — stale slices, a lost bucket — shows up here)
+    params_agree = True
+    if world > 1:
+        dp.consolidate()                                  # sharded mode: complete the master on every rank
+        a = model.param_arena
+        cs = a.flat_master[:a.total].double().abs().sum().reshape(1).to(cdev)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_agree = bool((hi - lo).abs().item() <= 1e-9 * max(1.0, abs(hi.item())))
     if rank == 0:
         global_batch = args.batch_per_gpu * world
         value = global_batch * args.steps / dt
@@ -231,6 +269,7 @@ def main(argv=None):
             "metric": "train images/sec (whole node) VGG16 bf16 224px",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "ms_first5": ms_first, "ms_last5": ms_last,      # GPU time per step over the first / last 5 timed steps (rank 0)
             "scaling": "weak",
             "vs_baseline": (value / (stock_img_s(args.batch_per_gpu)[0] * world)) if (on_gpu and plain) else None,
             "baseline": "stock PyTorch-ROCm bf16 channels_last on 1 MI355X (%.0f img/s at per-GPU batch %d) x "
@@ -245,6 +284,7 @@ def main(argv=None):
             "ranks_seen": ranks_seen,
             "grad_transport": type(tr).__name__,
             "grad_transport_selfcheck_ok": transport_ok,
+            "params_agree_across_ranks": params_agree,
             "native_transport_fell_back": bool(info.get("fell_back", False)),
             "native_transport_fallback_reason": info.get("reason"),
             "bucket_mbytes": [round(b["mbytes"], 3) for b in dp.reducer.bucket_summary()],
@@ -255,7 +295,8 @@ def main(argv=None):
                        "global_batch": global_batch, "image_size": args.image_size,
                        "seq_len": None, "parallelism": "dp%d" % world,
                        "optimizer": "fused SGD momentum 0.9 wd 1e-4, fp32 master weights%s" % (
-                           ", sharded per bucket (reduce-scatter + all-gather)" if dp.reducer.sharded else ""),
+                           ", sharded per bucket (reduce-scatter + all-gather)" if dp.reducer.sharded else
+                           ", per bucket behind its all-reduce" if dp.reducer.fused_update else ""),
                        "grad_dtype": args.grad_dtype if on_gpu else "fp32", "grad_accum": args.grad_accum,
                        "fp8_classifier": bool(args.fp8_classifier), "backend": backend,
                        "grad_transport": type(tr).__name__}}), flush=True)
@@ -270,9 +311,9 @@ def main(argv=None):
     dp.close()
     if world > 1:
         dist.destroy_process_group()
-    if not transport_ok or ranks_seen != world:
-        raise SystemExit("gradient transport self-check failed (ok=%s, ranks seen %d of %d)"
-                         % (transport_ok, ranks_seen, world))
+    if not transport_ok or ranks_seen != world or not params_agree:
+        raise SystemExit("gradient transport self-check failed (ok=%s, ranks seen %d of %d, parameters agree: %s)"
+                         % (transport_ok, ranks_seen, world, params_agree))
 
 
 if __name__ == "__main__":
