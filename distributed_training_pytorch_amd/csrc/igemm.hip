@@ -86,6 +86,7 @@ DTP_DEVINL f32x4_t mma16(const bf16x8_t& w, const bf16x8_t& x, f32x4_t c) {
 template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmParams p) {
   static_assert(!FP8 || (PIPE == 0 && !TAPS9), "fp8 operands: plain GEMM, 2-stage loop only");
+  static_assert(PIPE != 3 || TAPS9, "shared-image schedule is a 3x3 convolution schedule");
   constexpr int ES = FP8 ? 1 : 2;     // operand element size; a K-step is always 128 bytes per row
   constexpr int T = WGM * WGN * 64;
   constexpr int RP = T / 8;          // tile rows covered by one staging pass (8 lanes per 128-B row)
@@ -360,11 +361,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int tap; long ka, kb;
       koffs(T, tap, ka, kb);
       const bool live = T < kend;
-#ifdef DTP_DIAG_SKIP_A_DX
-      // DIAGNOSTIC (wrong math): the dx = -1 / +1 taps reuse whatever A image is in the slot — the
-      // traffic of a kernel that stages one activation image per tap ROW (upper bound of that design)
-      if (TAPS9 && (tap % 3) != 1) return;
-#endif
       char* dst = smem + d * DB + h * SA + wave * 1024;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
@@ -469,10 +465,242 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
 #undef DTP_PHASE_SYNC_OUT
   }
 
+  // ======================= PIPE == 3: 8-phase schedule over ONE activation image per tap ROW ===========
+  // The three dx taps of a filter row read the same 64-channel activation rows shifted by one pixel:
+  // tile row R, tap (dy, dx) = flat pixel m0 + R + dy*W + dx.  PIPE 2 stages those rows three times
+  // (3 x 32 KB per tap row and channel chunk); here they are staged ONCE as an image of 258 rows
+  // (pixels m0-1+dy*W .. m0+256+dy*W) and the fragment reads of tap dx start dx rows further down.
+  // A-operand LDS-DMA (and L2 reads) drop from 12 to 5 global_load_lds per lane and 3 K-tiles; the
+  // kernels are power-limited (docs/ROUND_NOTES.md), so fewer bytes through L2 and LDS per MFMA is
+  // what buys clock.  (Diagnostic upper bound, round 3: same kernel with the dx = +-1 A loads simply
+  // skipped: +8 % forward, +10-16 % data gradient on the 256/512-channel layers.)
+  //  * dy borders (and M tails) are decided per IMAGE ROW at staging time as before (zero page);
+  //  * dx borders cannot be: an image row is a legitimate operand for two of its three consumers.
+  //    They are per (output pixel, tap) = per lane and fragment: lanes whose pixel sits at w == 0
+  //    (dx = -1) or w == W-1 (dx = +1) read their fragment from a zeroed LDS region instead — ONE
+  //    v_cndmask per ds_read_b128 on the address, selected by wave masks kept in SGPR pairs;
+  //  * K order: (channel chunk, dy) super-tiles of three K-tiles (dx = -1, 0, +1); B (weights) keeps
+  //    PIPE 2's half-tile slots and issue points; the image of super-tile S+1 is issued in the even
+  //    phases of super-tile S (chunk 0 + halo, 1, 2, 3: rows 64c .. 64c+63; halo = rows 256, 257);
+  //  * the loop body is two super-tiles = 24 phases (image double buffer x B double buffer), every
+  //    phase with its own COUNTED vmcnt (derivation: docs/KERNELS.md "shared activation image").
+  if constexpr (PIPE == 3) {
+    static_assert(TAPS9 && WGM == 2 && WGN == 4 && BM == 256 && BN == 256, "shared-image schedule: 256x256, 2x4 waves");
+    constexpr int IMG = 264 * 128;            // one image: 258 rows used, 264 staged (wave-granular DMA)
+    constexpr int SB = WGN * 4096;            // B half-tile slot: 32 rows per wave column (as PIPE 2)
+    constexpr int BOFF = 2 * IMG;             // LDS: [img 0][img 1][B: dbuf x {B0, B1}][zeros]
+    constexpr int ZOFF = BOFF + 4 * SB;
+    constexpr int ZSZ = 8192 + 3 * 2048 + 512;     // largest fragment-read immediate + a row, rounded
+    static_assert(ZOFF + ZSZ <= 160 * 1024 && IMG + 8192 + 3 * 2048 + 16 < 65536, "LDS budget / ds_read immediates");
+    constexpr int NB = WGN / 2;
+    const int NS = 3 * cchunks;               // super-tiles (host guarantees: even, no split-K)
+    const int grp = wm;                       // stagger group = wave row
+
+    // ---- zero region (also the dump target of the halo DMA slot of waves 1..7)
+    for (int o = tid * 16; o < ZSZ; o += T * 16) *(u32x4_t*)(smem + ZOFF + o) = (u32x4_t){0u, 0u, 0u, 0u};
+
+    // ---- staging through buffer descriptors (as wgrad2.hip): per-lane 32-bit byte offsets that never
+    // change, wave-uniform offsets in the scalar operand, rows outside the tensor / past Ncols zero-filled
+    // by the hardware's range check; an invalid image row (dy border, M tail) is an out-of-range offset.
+    // Image row r = 64c + srow (c = 0..3; c == 4: halo rows 256, 257 = lanes 0..15 of wave 0) holds the
+    // pixel m0 - 1 + r + dy*W; the descriptor starts W + 1 pixels before the tile so that every scalar
+    // offset is non-negative (what lies before the tensor is never addressed: those rows are invalid).
+    const int hw3 = p.H * p.W;
+    const int mp0 = m0 - 1 + srow;            // output pixel whose dx = 0 tap reads image row srow
+    unsigned am = 0;                          // 3 bits per chunk: row valid for dy = -1, 0, +1
+    {
+      const int step_h = 64 / p.W, step_w = 64 - step_h * p.W;
+      const int rem = (mp0 + hw3) % hw3;       // mp0 >= -1: pixel -1 walks on like the last pixel of an image
+      int h = rem / p.W;
+      int w = rem - h * p.W;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int m = mp0 + c * 64;
+        const bool ok = m >= 0 && m < p.M && (c < 4 || tid < 16);
+        const unsigned bits = (h > 0 ? 1u : 0u) | 2u | (h < p.H - 1 ? 4u : 0u);
+        am |= (ok ? bits : 0u) << (3 * c);
+        w += step_w;
+        h += step_h;
+        if (w >= p.W) { w -= p.W; ++h; }
+        while (h >= p.H) h -= p.H;
+      }
+    }
+    const long a_first = (long)(m0 - 1 - p.W) * p.C * 2;                       // may lie before the tensor
+    const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.A + a_first, (long)p.M * p.C * 2 - a_first);
+    const unsigned a_voff = (unsigned)((srow * p.C + lch * 8) * 2);
+    const unsigned cstride = (unsigned)(64 * p.C * 2);                         // bytes between two chunks' rows
+    auto issue_img = [&](auto c_, auto ib_, int dyi, unsigned soff) {          // chunk c of the super-tile at (dyi, soff)
+      constexpr int c = decltype(c_)::value, ib = decltype(ib_)::value;
+      const unsigned vo = ((am >> (3 * c + dyi)) & 1u) ? a_voff : DTP_OOB_OFF;
+      const int dst = c < 4 ? ib * IMG + c * 8192 + wave * 1024
+                            : (wave == 0 ? ib * IMG + 4 * 8192 : ZOFF + (wave - 1) * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)(smem + dst), 16, vo,
+                                               soff + c * cstride, 0, 0);
+    };
+    // B half-tiles: LDS row rho = 64*j + srow <-> tile row ((rho>>5)<<6) + h*32 + (rho&31), as PIPE 2
+    const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(p.B + (long)n0 * p.ldb * 2, (long)(p.Ncols - n0) * p.ldb * 2);
+    const unsigned b_voff = (unsigned)(((((srow >> 5) << 6) + (srow & 31)) * p.ldb + lch * 8) * 2);
+    const unsigned bstride_h = (unsigned)(32 * p.ldb * 2), bstride_j = (unsigned)(128 * p.ldb * 2);
+    auto issue_B3 = [&](auto h_, auto d_, unsigned kb) {                       // half-tile B_h of the K-tile at column kb
+      constexpr int h = decltype(h_)::value, d = decltype(d_)::value;
+      const int dst = BOFF + d * (2 * SB) + h * SB + wave * 1024;
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (__attribute__((address_space(3))) void*)(smem + dst + j * 8192), 16,
+                                                 b_voff, kb + h * bstride_h + j * bstride_j, 0, 0);
+    };
+    // wave-uniform K bookkeeping: super-tile S = 3*cc + dyi; its K-tiles' weight columns start at
+    // kb(S) + j*2C; its image at soffset si(S) (chunk c: + c*cstride)
+    const unsigned c2 = (unsigned)(p.C * 2);
+    auto kb_of = [&](int S) -> unsigned { const int cc = S / 3, dyi = S - cc * 3; return (unsigned)((3 * dyi * p.C + cc * 64) * 2); };
+    auto si_of = [&](int S) -> unsigned { const int cc = S / 3, dyi = S - cc * 3; return (unsigned)((dyi * p.W * p.C + cc * 64) * 2); };
+    auto dy_of = [&](int S) -> int { return S - (S / 3) * 3; };
+    // ---- fragment read addresses: image row of tile row R for tap dx is R + 1 + dx
+    const unsigned lds0 = lds_addr(smem);
+    unsigned fb[3][2];
+#pragma unroll
+    for (int dxi = 0; dxi < 3; ++dxi) {
+      const int rr = frow + dxi;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        fb[dxi][ks] = lds0 + (wm * 128 + rr) * 128 + (((ks * 4 + fk) ^ ((rr >> 1) & 7)) << 4);
+    }
+    const unsigned zb[2] = {lds0 + ZOFF, lds0 + ZOFF - IMG};       // + ib*IMG + immediate lands in the zero region
+    // ---- dx border masks: fragment f = 4h + i of this wave row = tile rows wm*128 + 16*f + frow.  A
+    // fragment's 16 pixels are lanes 0..15 (lanes l, l+16, l+32, l+48 hold the same pixel), so a mask is a
+    // 16-bit pattern: 16 patterns packed in 8 SGPRs, widened to a wave mask where they are used (SALU)
+    unsigned pm_m1[4], pm_p1[4];
+    {
+      const int step16 = 16 % p.W;
+      int w = (m0 + wm * 128 + frow) % p.W;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const unsigned b0 = (unsigned)__builtin_amdgcn_ballot_w64(w == 0) & 0xFFFFu;
+        const unsigned b1 = (unsigned)__builtin_amdgcn_ballot_w64(w == p.W - 1) & 0xFFFFu;
+        if (f & 1) { pm_m1[f >> 1] |= b0 << 16; pm_p1[f >> 1] |= b1 << 16; }
+        else { pm_m1[f >> 1] = b0; pm_p1[f >> 1] = b1; }
+        w += step16;
+        if (w >= p.W) w -= p.W;
+      }
+    }
+    auto wave_mask = [](unsigned packed, int f) -> unsigned long long {
+      const unsigned p16 = (f & 1) ? packed >> 16 : packed & 0xFFFFu;
+      const unsigned m32 = p16 | (p16 << 16);
+      return ((unsigned long long)m32 << 32) | m32;
+    };
+    bf16x8_t xa[2][4], b0f[2][2], b1f[2][2];
+    typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_t;
+#define DTP3_SEL(dst, normal, zero, mask) asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(normal), "v"(zero), "s"(mask))
+#define DTP3_READ_A(h, ib, dxi)                                                                       \
+  {                                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) {  \
+      unsigned a_ = fb[dxi][ks];                                                                      \
+      if ((dxi) == 0) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_m1[(4 * (h) + i) >> 1], 4 * (h) + i)); \
+      if ((dxi) == 2) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_p1[(4 * (h) + i) >> 1], 4 * (h) + i)); \
+      xa[ks][i] = *(lds_frag_t)(size_t)(a_ + ((ib) * IMG + (h) * 8192 + i * 2048));                   \
+    }                                                                                                 \
+  }
+#define DTP3_READ_B(h, d, dst)                                                                        \
+  {                                                                                                   \
+    const char* s_ = smem + BOFF + (d) * (2 * SB) + (h) * SB + (wn * 32) * 128;                       \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int j = 0; j < 2; ++j)    \
+        dst[ks][j] = *(const bf16x8_t*)(s_ + j * 2048 + (ks ? foff1 : foff0));                        \
+  }
+#define DTP3_MMA(mh, nh, bf)                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(mh) * 4 + i][(nh) * 2 + j] =                 \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], xa[ks][i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);
+#define DTP3_SYNC_IN(VM)                                      \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");   \
+  __builtin_amdgcn_s_barrier();                               \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+  __builtin_amdgcn_sched_barrier(0);                          \
+  __builtin_amdgcn_s_setprio(1);
+#define DTP3_SYNC_OUT()                                       \
+  __builtin_amdgcn_s_setprio(0);                              \
+  __builtin_amdgcn_sched_barrier(0);                          \
+  __builtin_amdgcn_s_barrier();                               \
+  __builtin_amdgcn_sched_barrier(0);
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    using J3 = std::integral_constant<int, 3>;
+    using J4 = std::integral_constant<int, 4>;
+    // One K-tile = four quadrant phases (A0B0, A0B1, A1B1, A1B0).  j = dx + 1, ib = image buffer,
+    // d = B double buffer of this K-tile (T & 1), S / T = its super-tile / K-tile index.
+    // DMA issue points:  q1: B1(T+1)   q2: image slot   q3: B0(T+2)   q4: image slot
+    //   image slots of a super-tile (next image, buffer 1-ib): (j0,q2) chunk 0 + halo, (j0,q4) chunk 1,
+    //   (j1,q2) chunk 2, (j1,q4) chunk 3, (j2,*) nothing.
+    // Counted waits (loads that may stay in flight behind the one the NEXT phase reads):
+    //   after q1: B1(T), issued at q1 of T-1   -> j0: 0+2+0+2 = 4,  j1: 2+2+1+2 = 7,  j2: 1+2+1+2 = 6
+    //   after q4: B0(T+1), issued at q3 of T-1 -> j0: 0+2+2+2+1 = 7, j1: 1+2+1+2+1 = 7,
+    //             j2: the whole next image as well (its last chunk went out at q4 of T-1): 2+2 = 4
+    //   q2, q3: the next phase reads nothing new (image rows are static within a super-tile)
+#define DTP3_TILE(j, ib, d, KB1, KB2, VQ1, VQ4, SLOT2, SLOT4)                                         \
+      DTP3_READ_A(0, ib, j) DTP3_READ_B(0, d, b0f)                                     /* q1 */       \
+      issue_B3(J1{}, std::integral_constant<int, 1 - (d)>{}, KB1);                                    \
+      DTP3_SYNC_IN(VQ1); DTP3_MMA(0, 0, b0f) DTP3_SYNC_OUT();                                         \
+      DTP3_READ_B(1, d, b1f)                                                           /* q2 */       \
+      SLOT2                                                                                           \
+      DTP3_SYNC_IN(63); DTP3_MMA(0, 1, b1f) DTP3_SYNC_OUT();                                          \
+      DTP3_READ_A(1, ib, j)                                                            /* q3 */       \
+      issue_B3(J0{}, std::integral_constant<int, (d)>{}, KB2);                                        \
+      DTP3_SYNC_IN(63); DTP3_MMA(1, 1, b1f) DTP3_SYNC_OUT();                                          \
+      SLOT4                                                                            /* q4 */       \
+      DTP3_SYNC_IN(VQ4); DTP3_MMA(1, 0, b0f) DTP3_SYNC_OUT();
+    // one super-tile: kb = its weight column, kbn / sin / dyn = weight column, image offset, dy index of the NEXT one
+#define DTP3_SUPER(ib, d0, kb, kbn, sin, dyn)                                                         \
+      DTP3_TILE(0, ib, d0, (kb) + c2, (kb) + 2 * c2, 4, 7,                                            \
+                issue_img(J0{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);                   \
+                issue_img(J4{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);,                  \
+                issue_img(J1{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);)                  \
+      DTP3_TILE(1, ib, 1 - (d0), (kb) + 2 * c2, (kbn), 7, 7,                                          \
+                issue_img(J2{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);,                  \
+                issue_img(J3{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);)                  \
+      DTP3_TILE(2, ib, d0, (kbn), (kbn) + c2, 6, 4, , )
+
+    // prologue (issue order = the steady state's: B0(0); image 0; B1(0); B0(1))
+    issue_B3(J0{}, J0{}, 0u);
+    issue_img(J0{}, J0{}, 0, 0u);
+    issue_img(J4{}, J0{}, 0, 0u);
+    issue_img(J1{}, J0{}, 0, 0u);
+    issue_img(J2{}, J0{}, 0, 0u);
+    issue_img(J3{}, J0{}, 0, 0u);
+    issue_B3(J1{}, J0{}, 0u);
+    issue_B3(J0{}, J1{}, c2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the zero-region stores
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();    // stagger the second wave row by one barrier
+    __builtin_amdgcn_sched_barrier(0);
+
+    DTP_STAMP(2)
+    for (int S = 0; S < NS; S += 2) {
+      // (loads issued for super-tiles >= NS at the tail read in-range garbage or hardware zeros into
+      // slots nobody reads any more; they only keep the counted waits uniform)
+      const unsigned kb0 = kb_of(S), kb1 = kb_of(S + 1), kb2 = kb_of(S + 2);
+      const unsigned si1 = si_of(S + 1), si2 = si_of(S + 2);
+      const int dy1 = dy_of(S + 1), dy2 = dy_of(S + 2);
+      DTP3_SUPER(0, 0, kb0, kb1, si1, dy1)         // K-tiles 3S .. 3S+2   (B dbuf 0, 1, 0)
+      DTP3_SUPER(1, 1, kb1, kb2, si2, dy2)         // K-tiles 3S+3 .. 3S+5 (B dbuf 1, 0, 1)
+    }
+    DTP_STAMP(3)
+    if (grp == 0) __builtin_amdgcn_s_barrier();    // pair the stagger barrier of the other group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain (dummy) DMA before the C image reuses LDS
+#undef DTP3_SUPER
+#undef DTP3_TILE
+#undef DTP3_SYNC_OUT
+#undef DTP3_SYNC_IN
+#undef DTP3_MMA
+#undef DTP3_READ_B
+#undef DTP3_READ_A
+#undef DTP3_SEL
+  }
+
   // ---------------- main loop: 2 LDS stages, one barrier per K-step
-  if (PIPE != 2 && kbeg < kend) stage(kbeg, 0);
+  if (PIPE < 2 && kbeg < kend) stage(kbeg, 0);
   int buf = 0;
-  if (PIPE == 2) {
+  if (PIPE >= 2) {
     // handled above
   } else if (PIPE == 0) {
     for (int kt = kbeg; kt < kend; ++kt) {
@@ -814,7 +1042,7 @@ static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Ncols + BN - 1) / BN;
-  constexpr int lds = 2 * (BM + BN) * 128;
+  constexpr int lds = PIPE == 3 ? 2 * 264 * 128 + 4 * (WGN * 4096) + (8192 + 3 * 2048 + 512) : 2 * (BM + BN) * 128;
   static bool attr_set = false;
   auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE, FP8>;
   if (!attr_set) {
@@ -894,6 +1122,10 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 12: rc = DTP_IG(128, 64, 2, 1, 1); break;
     case 16: rc = DTP_IG(256, 256, 2, 4, 2); break;   // 8-phase, counted vmcnt
     case 17: rc = DTP_IG(512, 128, 4, 2, 2); break;   // 8-phase for outputs of <= 128 channels
+    case 18:        // 8-phase over one staged activation image per tap row (3x3 only, C % 128 == 0, no split-K)
+      if (!t9 || nsplit != 1 || (C & 127)) return -22;
+      rc = launch_cfg<256, 256, 2, 4, true, 3>(p, nsplit, stream);
+      break;
     default: return -16;
   }
 #undef DTP_IG

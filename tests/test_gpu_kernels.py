@@ -401,7 +401,7 @@ def test_conv1_fprop_wgrad(shape, in_dtype):
     assert not torch.equal(g1, gw.float()) or (y.float() > 0).all()
 
 
-@pytest.mark.parametrize("cfg", [16, 17])
+@pytest.mark.parametrize("cfg", [16, 17, 18])
 @pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (3, 9, 11, 64, 256), (2, 56, 56, 256, 256),
                                    (3, 30, 26, 128, 128)])
 def test_conv3x3_8phase_schedule(shape, cfg):
@@ -426,13 +426,55 @@ def test_conv3x3_8phase_schedule(shape, cfg):
             assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16, 17])
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 256), (2, 14, 14, 512, 512), (2, 56, 56, 256, 256), (3, 30, 26, 128, 128),
+                                   (3, 9, 11, 256, 320), (5, 7, 5, 128, 256), (1, 40, 3, 128, 256), (2, 112, 112, 128, 64),
+                                   (300, 2, 2, 128, 256), (1, 16, 16, 384, 256), (2, 33, 16, 128, 256)])
+def test_conv3x3_shared_activation_image_schedule(shape):
+    """cfg 18 (csrc/igemm.hip PIPE 3): the three dx taps of a filter row read ONE staged activation
+    image; the dx borders are per-lane selects of a zeroed LDS region, the dy borders per-row zero
+    fill at staging.  Same reduction order as cfg 16 -> bit-identical to it, forward and masked data
+    gradient (with the 1-bit masks, column sums and BatchNorm statistics of the shared epilogue), on
+    widths from 2 to 112 (borders in every lane position, several per 16-pixel fragment, W = 16 where
+    every fragment starts at w == 0), M and N tails, images smaller than a tile, and repeated runs."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(61)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda")
+    ref = _ref_conv(x, w, b, True)
+    y16, bits16 = _with_cfg(k, 16, lambda: k.conv3x3_fprop(x, w, b, relu=True, want_bits=True))
+    outs = [_with_cfg(k, 18, lambda: k.conv3x3_fprop(x, w, b, relu=True, want_bits=True)) for _ in range(3)]
+    _close(outs[0][0], ref, 2e-2, 2e-2, "shared-image fprop%s" % (shape,))
+    for y, bits in outs:
+        assert torch.equal(y, y16), "cfg 18 != cfg 16 %s: %g" % (shape, (y.float() - y16.float()).abs().max().item())
+        assert torch.equal(bits, bits16)
+    # masked data gradient of a layer with Co inputs (reduction over Co: needs Co % 128 == 0)
+    if Co % 128 == 0:
+        dy = _rand(N, H, W, Co, scale=0.1)
+        wd = _rand(C, 9 * Co, scale=(2.0 / (9 * Co)) ** 0.5)
+        d16 = _with_cfg(k, 16, lambda: k.conv3x3_dgrad(dy, wd, mask_src=x))
+        cs16 = torch.empty(C, device="cuda")
+        k.bias_grad(d16.view(-1, C), cs16)
+        d18 = _with_cfg(k, 18, lambda: k.conv3x3_dgrad(dy, wd, mask_src=x))
+        assert k.colsum_slot.tensor is d18
+        cs18 = torch.empty(C, device="cuda")
+        k.bias_grad(d18.view(-1, C), cs18)
+        assert torch.equal(d16, d18) and torch.equal(cs16, cs18)
+        w4 = wd.float().view(C, 3, 3, Co)        # wd[ci][t][co] = w[co][8-t][ci]: reference through the plain conv
+        refd = F.conv2d(dy.float().permute(0, 3, 1, 2), w4.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1) * (x.float() > 0)
+        _close(d18, refd, 2e-2, 2e-2 * refd.abs().max().item(), "shared-image dgrad%s" % (shape,))
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16, 17, 18])
 def test_fused_bias_grad_from_dgrad_epilogue(cfg):
     """The masked data-gradient kernel leaves per-tile column sums of its output behind; the
     consumer's bias gradient built from them equals the column sum of the stored bf16 tensor."""
     k = _k()
     torch.manual_seed(11)
     N, H, W, C, Co = 3, 18, 14, 192, 128          # M = 756: row tail in every tile size
+    if cfg == 18:
+        k.igemm_shared_a = True                    # (Co = 128 reduction channels: the shared-image schedule applies)
     dy = _rand(N, H, W, Co)
     wd = _rand(C, 9 * Co, scale=(2.0 / (9 * Co)) ** 0.5)
     xmask = _rand(N, H, W, C)
@@ -627,7 +669,7 @@ def test_relu_bitmask_roundtrip(shape):
     C2 = 128
     dy = _rand(N, H, W, C2)
     wd = _rand(Co, 9 * C2, scale=(2.0 / (9 * C2)) ** 0.5)
-    for cfg in (None, 3, 16, 17):
+    for cfg in (None, 3, 16, 17, 18):
         if cfg is not None:
             k._overrides["igemm"] = lambda M, Nc, ks, cfg=cfg: (cfg, 1)
         try:
