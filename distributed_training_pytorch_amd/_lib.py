@@ -65,6 +65,7 @@ _SIGS = {
                               c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p],
     "dtp_bn_bwd_pool": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                         c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "dtp_augment_u8": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_sgd_flat": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
                      c_float, c_float, c_int, c_int, c_void_p],
     "dtp_adamw_flat": [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,

@@ -34,6 +34,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+from .device_augment import brightness_contrast_u8, gamma_u8
 from .synthetic import IMAGENET_MEAN, IMAGENET_STD
 
 IMG_EXT = (".jpg", ".jpeg", ".png", ".bmp", ".ppm", ".webp")
@@ -145,21 +146,31 @@ class ExampleDataset(Dataset):
             ycc[..., 0] = clahe(ycc[..., 0], clip_limit=r.uniform(1.0, 4.0), grid=(8, 8))
             img = Image.fromarray(ycc, mode="YCbCr").convert("RGB")
         if r.random() < p:
-            a = np.asarray(img, dtype=np.float32)
             alpha = 1.0 + r.uniform(-0.2, 0.2)
             beta = r.uniform(-0.2, 0.2) * 255.0
-            a = np.clip(a * alpha + beta, 0, 255)
-            img = Image.fromarray(a.astype(np.uint8))
+            img = Image.fromarray(brightness_contrast_u8(np.asarray(img), alpha, beta))     # shared with the device pipeline
         if r.random() < p:
-            gamma = r.uniform(0.8, 1.2)
-            a = np.asarray(img, dtype=np.float32) / 255.0
-            img = Image.fromarray((np.power(a, gamma) * 255.0).astype(np.uint8))
+            img = Image.fromarray(gamma_u8(np.asarray(img), r.uniform(0.8, 1.2)))
         if r.random() < p:
             buf = io.BytesIO()
             img.save(buf, format="JPEG", quality=r.randint(20, 100))
             buf.seek(0)
             img = Image.open(buf).convert("RGB")
         return img
+
+    def load_raw(self, idx):
+        """Decoded, resized, UN-augmented sample as (uint8 CHW tensor, label): what the HBM cache of
+        ``data/device_cache.py`` holds; augmentation then runs on the device (``data/device_augment.py``)."""
+        Image, _, _ = _pil()
+        path, lb = self.data_list[idx]
+        img = Image.open(path).convert("RGB").resize((self.width, self.height), Image.BILINEAR)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1))), lb
+
+    def device_augmenter(self):
+        """The device-side stand-in for ``_augment`` (rot90 / flips / brightness-contrast / gamma; blur,
+        median, CLAHE and JPEG stay CPU-only), drawing from (seed, epoch, index) like the CPU pipeline."""
+        from .device_augment import DeviceAugmenter
+        return DeviceAugmenter(seed=self.seed, prob=self.prob) if self.phase == "train" else None
 
     def __getitem__(self, idx):
         Image, _, _ = _pil()

@@ -485,7 +485,11 @@ class Trainer(object):
             sampler = ShardedSampler(len(dataset), self.world_rank, self.world_size, shuffle=False, pad=False)
         if (self.cache_dataset_on_device and self.device.type == "cuda" and collate_fn is None
                 and DeviceCachedLoader.fits(dataset, self.device)):
-            return DeviceCachedLoader(dataset, batch_size, sampler, self.device)
+            try:
+                # un-augmented samples in HBM; training-phase augmentation runs on the device per batch
+                return DeviceCachedLoader(dataset, batch_size, sampler, self.device)
+            except ValueError as e:      # a CPU-augmenting dataset without raw access: never freeze its draws
+                self.log("cache_dataset_on_device refused: %s - using the DataLoader" % e, "warning")
         return DataLoader(dataset, batch_size=batch_size, pin_memory=pin_memory, shuffle=False,
                           sampler=sampler, collate_fn=collate_fn, num_workers=self.num_workers,
                           # datasets with per-epoch state (set_epoch) get fresh workers every epoch so

@@ -1115,3 +1115,34 @@ def test_batchnorm_backward_reductions_from_the_data_gradient_epilogue(shape, cf
     assert (db1 - db0).abs().max().item() < 1e-4 * dyh.abs().sum(0).max().item()
     assert (dg1 - dg0).abs().max().item() < 2e-4 * dyh.abs().sum(0).max().item()
     _close(dy1, dy0.float(), 1e-2, 1e-2 * dy0.float().abs().max().item(), "bn_bwd dy from epilogue reductions")
+
+
+@pytest.mark.parametrize("shape", [(12, 3, 40, 40), (5, 3, 24, 41), (3, 1, 130, 130), (2, 3, 224, 224)])
+def test_device_augmentation_matches_numpy(shape):
+    """csrc/augment.hip (gather + rot90 / h-flip / v-flip + per-sample brightness-contrast / gamma table)
+    against the numpy pipeline of data/device_augment.augment_reference, which uses the very expressions
+    of the CPU dataset (data/image_folder.py): bit-identical, for square and non-square images, odd
+    widths, several 64-row bands, with and without the gather."""
+    import numpy as np
+    from distributed_training_pytorch_amd import _lib
+    from distributed_training_pytorch_amd._lib import check, ptr, stream
+    from distributed_training_pytorch_amd.data import device_augment as da
+    N, C, H, W = shape
+    rs = np.random.RandomState(7)
+    cache = rs.randint(0, 256, size=(N + 9, C, H, W), dtype=np.uint8)
+    sel = rs.permutation(N + 9)[:N].astype(np.int64)
+    p = da.draw_params(sel, epoch=3, seed=11, prob=0.7, square=(H == W))
+    assert H != W or N < 8 or len(set(p["k"].tolist())) > 1          # quarter turns really drawn
+    ref = da.augment_reference(cache[sel], p)
+    x = torch.from_numpy(cache).cuda()
+    out = da.DeviceAugmenter(seed=11, prob=0.7)(x, torch.from_numpy(sel).cuda(), sel, 3)
+    torch.cuda.synchronize()
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (N, C, H, W)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # identity: no geometry, no table, no gather
+    out2 = torch.empty_like(x)
+    check(_lib.hip().dtp_augment_u8(ptr(x), None, None, None, ptr(out2), N + 9, C, H, W, 1, stream()), "augment_u8")
+    assert torch.equal(out2, x)
+    # other epoch / other seed -> other draws
+    p2 = da.draw_params(sel, epoch=4, seed=11, prob=0.7, square=(H == W))
+    assert not np.array_equal(da.geom_codes(p), da.geom_codes(p2)) or N < 4

@@ -101,12 +101,117 @@ def test_forward_backward_matches_reference(grad_dtype, size):
         ge = ref_grads[name]
         c_emu = cos(gg.flatten(), ge.flatten(), dim=0).item()
         ratio = gg.norm().item() / (ge.norm().item() + 1e-20)
-        # bias gradients are 64..4096-element sums with heavy cancellation: a few flipped ReLU
-        # masks (bf16 accumulation-order noise) move them more than the weight gradients
-        lo, hi, cmin = (0.85, 1.15, 0.93) if name.endswith("bias") else (0.95, 1.05, 0.95)
+        # Per-layer thresholds from the measured minima over 12 configurations (bench/measure_grad_parity.py,
+        # profiles/68_grad_parity_per_layer.jsonl): linear3's gradient has no ReLU mask of its own (0.9998);
+        # every other layer's contains masks that flip where a pre-activation sits within bf16 noise of 0
+        # (the net is randomly initialised: linear outputs ~1e-3) — linear2 0.986, linear1 / block 5 0.975-0.982,
+        # blocks 3-4 0.969-0.975, blocks 1-2 0.961-0.974; bias gradients are 64..4096-element sums with heavy
+        # cancellation and move more (0.946 at conv1_2).  The tight, mask-independent check is
+        # test_layerwise_teacher_forced_gradients_are_tight below.
+        if name.startswith("linear3"):
+            lo, hi, cmin = 0.995, 1.005, 0.999
+        elif name.startswith("linear"):
+            lo, hi, cmin = 0.98, 1.02, 0.975
+        elif name.startswith(("backbone.3", "backbone.4")):
+            lo, hi, cmin = 0.97, 1.03, 0.96
+        elif name.endswith("bias"):
+            lo, hi, cmin = 0.90, 1.10, 0.93
+        else:
+            lo, hi, cmin = 0.95, 1.05, 0.95
         assert c_emu > cmin and lo < ratio < hi, "%s: vs emulated ref cos %.4f norm ratio %.4f" % (name, c_emu, ratio)
         c_cpu = cos(gg.flatten().cpu(), pc.grad.flatten(), dim=0).item()
         assert c_cpu > 0.85, "%s: vs fp32 CPU cos %.4f" % (name, c_cpu)
+
+
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
+def test_layerwise_teacher_forced_gradients_are_tight(grad_dtype):
+    """The model-level check above compares against a reference that re-runs the WHOLE net: ~1 % of the
+    ReLU masks flip under bf16 rounding and decorrelate deep-layer gradients (measured minimum cosine
+    0.946-0.987, bench/measure_grad_parity.py -> profiles/68_*), so its thresholds cannot catch a 5 %
+    wiring error.  This one can.  One real forward/backward of the fused VGG16 (conv+pool fusion off so
+    that every layer runs through its module); hooks capture each layer's GPU input, output and incoming
+    gradient; every layer is then recomputed on its OWN captured tensors with plain fp32 torch ops —
+    same operand bits, same masks (the GPU activation's own sign), only the summation order differs —
+    and its weight, bias and data gradient must agree to cosine >= 0.9999 (fp32 gradient arena; 0.999
+    with a bf16 arena: one rounding per element) and a norm ratio within 0.5 %.  Checks the contracts
+    between layers: which tensor is saved, who applies whose ReLU mask (grad_premasked /
+    input_is_relu_out / conv1_1's self-mask), bias gradients from producer epilogues, flatten order."""
+    import torch.nn.functional as F
+    from distributed_training_pytorch_amd.ops import kernels as K
+    from distributed_training_pytorch_amd.ops.layers import Conv3x3, ConvFirst, Linear, SoftmaxCrossEntropy
+    _, gpu = _models(size=64, grad_dtype=grad_dtype, seed=3)
+    torch.manual_seed(4)
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 3, (8,), device="cuda")
+    cap = {}
+
+    def hook(name):
+        def fn(mod, inp, out):
+            rec = cap.setdefault(name, {})
+            rec["x"], rec["y"] = inp[0].detach(), out.detach()
+            out.register_hook(lambda g, rec=rec: rec.__setitem__("gy", g.detach()))
+            if inp[0].requires_grad:
+                inp[0].register_hook(lambda g, rec=rec: rec.__setitem__("gx", g.detach()))
+        return fn
+
+    layers = [(n, m) for n, m in gpu.named_modules() if isinstance(m, (Conv3x3, ConvFirst, Linear))]
+    handles = [m.register_forward_hook(hook(n)) for n, m in layers]
+    K.fuse_conv_pool = False
+    try:
+        gpu.train()
+        SoftmaxCrossEntropy()(gpu(x), y).backward()
+        torch.cuda.synchronize()
+    finally:
+        K.fuse_conv_pool = True
+        for h in handles:
+            h.remove()
+    a = gpu.param_arena
+    cos = lambda u, v: F.cosine_similarity(u.flatten().double(), v.flatten().double(), dim=0).item()   # noqa: E731
+    cmin = 0.9999 if grad_dtype == torch.float32 else 0.999
+    checked = 0
+    for name, m in layers:
+        rec = cap[name]
+        w = m.weight.detach().bfloat16().float()
+        b = m.bias.detach().float()
+        gy = rec["gy"].float()
+        yv = rec["y"].float()
+        if isinstance(m, Linear):
+            xin = rec["x"].float()
+            g = gy if (m.grad_premasked or not m.relu) else gy * (yv > 0)
+            pre = xin @ w.t() + b
+            ref_y = F.relu(pre) if m.relu else pre
+            gw, gb, gx = g.t() @ xin, g.sum(0), g @ w
+            if m.input_is_relu_out:
+                gx = gx * (xin > 0)
+        else:
+            if isinstance(m, ConvFirst):
+                xin = rec["x"].float().bfloat16().float()                    # NCHW image, rounded by the ingest
+                y_nchw, g_nchw = yv.permute(0, 3, 1, 2), gy.permute(0, 3, 1, 2)
+            else:
+                xin = rec["x"].float().permute(0, 3, 1, 2)                   # NHWC bf16 activation
+                y_nchw, g_nchw = yv.permute(0, 3, 1, 2), gy.permute(0, 3, 1, 2)
+            g = g_nchw if (m.grad_premasked or not m.relu) else g_nchw * (y_nchw > 0)
+            pre = F.conv2d(xin, w, b, padding=1)
+            ref_y = (F.relu(pre) if m.relu else pre)
+            gw = torch.nn.grad.conv2d_weight(xin, w.shape, g.contiguous(), padding=1)
+            gb = g.sum((0, 2, 3))
+            gx = F.conv_transpose2d(g.contiguous(), w, padding=1)
+            if getattr(m, "input_is_relu_out", False):
+                gx = gx * (xin > 0)
+            ref_y, gx = ref_y.permute(0, 2, 3, 1), gx.permute(0, 2, 3, 1)
+        # forward: one bf16 rounding (fp32 logits: accumulation order only)
+        err = (yv - ref_y).abs().max().item()
+        assert err <= 0.01 * ref_y.abs().max().item() + 1e-5, "%s forward: max err %g" % (name, err)
+        got_w = a._logical_view(a.flat_grad, a.index[id(m.weight)]).float()
+        got_b = a._logical_view(a.flat_grad, a.index[id(m.bias)]).float()
+        for what, got, ref in (("weight", got_w, gw), ("bias", got_b, gb)):
+            c, r = cos(got, ref), got.norm().item() / (ref.norm().item() + 1e-30)
+            assert c >= cmin and abs(r - 1) < 5e-3, "%s %s gradient: cos %.6f norm ratio %.5f" % (name, what, c, r)
+        if "gx" in rec:
+            c, r = cos(rec["gx"].float(), gx), rec["gx"].float().norm().item() / (gx.norm().item() + 1e-30)
+            assert c >= 0.9999 and abs(r - 1) < 5e-3, "%s data gradient: cos %.6f norm ratio %.5f" % (name, c, r)
+        checked += 1
+    assert checked == 16
 
 
 def test_training_reduces_loss_and_checkpoint_roundtrip(tmp_path):

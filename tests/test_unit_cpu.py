@@ -520,3 +520,71 @@ def test_topk_hits_matches_sklearn_top_k_accuracy_score():
     z = torch.zeros(5, 4)
     assert ev.topk_hits(z, torch.tensor([3, 3, 2, 1, 0]), 1) == 2
     assert ev.topk_hits(z, torch.tensor([3, 3, 2, 1, 0]), 2) == 3
+
+
+def _write_image_folder(root, labels, n_per_class, size):
+    import numpy as np
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for lb in labels:
+        os.makedirs(os.path.join(root, lb), exist_ok=True)
+        for i in range(n_per_class):
+            Image.fromarray(rs.randint(0, 256, size=(size + 3, size + 5, 3), dtype=np.uint8)).save(
+                os.path.join(root, lb, "%03d.png" % i))
+
+
+def test_device_cache_holds_raw_images_and_refuses_frozen_augmentation(tmp_path):
+    """DeviceCachedLoader (round 2 cached dataset[i]: one augmentation draw per image forever): a
+    training-phase ExampleDataset is cached UN-augmented (load_raw) and gets a device augmenter; a
+    dataset that augments on the CPU without raw access is refused; validation phases and synthetic
+    sets are cached as they are."""
+    import numpy as np
+    from distributed_training_pytorch_amd.data.device_cache import DeviceCachedLoader
+    from distributed_training_pytorch_amd.data.image_folder import ExampleDataset
+    from distributed_training_pytorch_amd.data.synthetic import SyntheticImageDataset
+    from distributed_training_pytorch_amd.parallel.sampler import ShardedSampler
+    root = str(tmp_path / "img")
+    _write_image_folder(root, ["a", "b"], 5, 16)
+    ds = ExampleDataset(root, ["a", "b"], 16, 16, phase="train", uint8=True)
+    raw0, _ = ds.load_raw(0)
+    assert raw0.dtype == torch.uint8 and tuple(raw0.shape) == (3, 16, 16)
+    samp = ShardedSampler(len(ds), 0, 1, shuffle=False, pad=False)
+    ld = DeviceCachedLoader(ds, 4, samp, "cpu", max_bytes=1 << 30)
+    assert ld.raw and ld.augmenter is not None
+    batches = list(ld)
+    assert sum(b[0].shape[0] for b in batches) == 10
+    got = torch.cat([b[0] for b in batches])
+    want = torch.stack([ds.load_raw(i)[0] for i in range(10)])
+    assert torch.equal(got, want)                       # the cache holds the un-augmented pixels
+    # float pipeline: normalised on the loader side exactly like __getitem__ of the val phase
+    dsf = ExampleDataset(root, ["a", "b"], 16, 16, phase="train", uint8=False)
+    dsv = ExampleDataset(root, ["a", "b"], 16, 16, phase="val", uint8=False)
+    xf = torch.cat([b[0] for b in DeviceCachedLoader(dsf, 4, samp, "cpu", max_bytes=1 << 30)])
+    xv = torch.stack([dsv[i][0] for i in range(10)])
+    assert torch.allclose(xf, xv, atol=1e-6)
+    ldv = DeviceCachedLoader(dsv, 4, samp, "cpu", max_bytes=1 << 30)
+    assert not ldv.raw and ldv.augmenter is None
+
+    class CpuAugOnly(torch.utils.data.Dataset):
+        phase = "train"
+
+        def _augment(self, img):
+            return img
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return torch.zeros(3, 4, 4), 0
+
+    with pytest.raises(ValueError, match="freeze"):
+        DeviceCachedLoader(CpuAugOnly(), 2, ShardedSampler(4, 0, 1, shuffle=False, pad=False), "cpu", max_bytes=1 << 20)
+    syn = SyntheticImageDataset(6, 3, 8, 8)
+    assert not DeviceCachedLoader(syn, 2, ShardedSampler(6, 0, 1, shuffle=False, pad=False), "cpu", max_bytes=1 << 20).raw
+    # the CPU pipeline's brightness-contrast / gamma are the functions the device tables are built from
+    from distributed_training_pytorch_amd.data import device_augment as da
+    p = da.draw_params(np.arange(64), epoch=1, seed=2, prob=1.0)
+    lut = da.compose_lut(p)
+    for n in (0, 17, 63):
+        v = np.arange(256, dtype=np.uint8)
+        assert np.array_equal(lut[n], da.gamma_u8(da.brightness_contrast_u8(v, p["alpha"][n], p["beta"][n]), p["gamma"][n]))
