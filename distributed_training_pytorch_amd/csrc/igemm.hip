@@ -485,16 +485,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   //  * the loop body is two super-tiles = 24 phases (image double buffer x B double buffer), every
   //    phase with its own COUNTED vmcnt (derivation: docs/KERNELS.md "shared activation image").
   if constexpr (PIPE == 3) {
-    static_assert(TAPS9 && WGM == 2 && WGN == 4 && BM == 256 && BN == 256, "shared-image schedule: 256x256, 2x4 waves");
-    constexpr int IMG = 264 * 128;            // one image: 258 rows used, 264 staged (wave-granular DMA)
+    // Two geometries, both 8 waves whose tile is 64 channels wide: 256x256 as 2x4 waves of 128x64 (cfg 18)
+    // and 384x128 as 4x2 waves of 96x64 (cfg 19, outputs of <= 128 channels: two 520-row images + the
+    // weights of a 512x128 tile do not fit the 160 KB of LDS).
+    static_assert(TAPS9 && WGM * WGN == 8 && BN == WGN * 64 && BM == WGM * (BM / WGM) && ((BM / WGM) % 32) == 0 &&
+                  BM % 64 == 0, "shared-image schedule: 8 waves, 64 output channels per wave");
+    constexpr int WR = BM / WGM;              // pixel rows per wave row (128 / 96)
+    constexpr int FH = WR / 32;               // 16-row fragments per half of a wave's rows (4 / 3)
+    constexpr int HS = FH * 2048;             // bytes between the two halves' first rows
+    constexpr int NCH = BM / 64;              // 64-row staging chunks per image (4 / 6), + the halo chunk
+    constexpr int IMG = (BM + 8) * 128;       // one image: BM + 2 rows used, BM + 8 staged (wave-granular DMA)
     constexpr int SB = WGN * 4096;            // B half-tile slot: 32 rows per wave column (as PIPE 2)
     constexpr int BOFF = 2 * IMG;             // LDS: [img 0][img 1][B: dbuf x {B0, B1}][zeros]
     constexpr int ZOFF = BOFF + 4 * SB;
-    constexpr int ZSZ = 8192 + 3 * 2048 + 512;     // largest fragment-read immediate + a row, rounded
-    static_assert(ZOFF + ZSZ <= 160 * 1024 && IMG + 8192 + 3 * 2048 + 16 < 65536, "LDS budget / ds_read immediates");
+    constexpr int ZSZ = (2 * FH - 1) * 2048 + 512;     // largest fragment-read immediate + a row, rounded
+    static_assert(ZOFF + ZSZ <= 160 * 1024 && IMG + ZSZ < 65536 && ZSZ >= 7 * 1024, "LDS budget / ds_read immediates / halo dump");
     constexpr int NB = WGN / 2;
     const int NS = 3 * cchunks;               // super-tiles (host guarantees: even, no split-K)
-    const int grp = wm;                       // stagger group = wave row
+    const int grp = wm * 2 / WGM;             // stagger group: upper / lower half of the wave rows
+    // image chunks per even-phase slot of a super-tile (slot order (j0,q2) (j0,q4) (j1,q2) (j1,q4) (j2,q2)
+    // (j2,q4)); the halo rides with chunk 0; the last chunk goes out at (j1,q4): 5 phases before its first read
+    constexpr int L0 = NCH == 4 ? 2 : 3, L1 = NCH == 4 ? 1 : 2, L2 = 1, L3 = 1, L4 = 0, L5 = 0;
+    static_assert((NCH == 4 || NCH == 6) && L0 + L1 + L2 + L3 + L4 + L5 == NCH + 1, "chunk -> slot plan");
+    // counted waits (loads that may stay in flight behind the one the NEXT phase reads; derivation below)
+    constexpr int VQ1_0 = L4 + L5 + 2 * NB, VQ1_1 = L0 + L1 + 2 * NB, VQ1_2 = L2 + L3 + 2 * NB;
+    constexpr int VQ4_0 = L5 + L0 + L1 + 2 * NB, VQ4_1 = L1 + L2 + L3 + 2 * NB, VQ4_2 = L4 + L5 + 2 * NB;
 
     // ---- zero region (also the dump target of the halo DMA slot of waves 1..7)
     for (int o = tid * 16; o < ZSZ; o += T * 16) *(u32x4_t*)(smem + ZOFF + o) = (u32x4_t){0u, 0u, 0u, 0u};
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     // ---- staging through buffer descriptors (as wgrad2.hip): per-lane 32-bit byte offsets that never
     // change, wave-uniform offsets in the scalar operand, rows outside the tensor / past Ncols zero-filled
     // by the hardware's range check; an invalid image row (dy border, M tail) is an out-of-range offset.
-    // Image row r = 64c + srow (c = 0..3; c == 4: halo rows 256, 257 = lanes 0..15 of wave 0) holds the
+    // Image row r = 64c + srow (c < NCH; c == NCH: halo rows BM, BM + 1 = lanes 0..15 of wave 0) holds the
     // pixel m0 - 1 + r + dy*W; the descriptor starts W + 1 pixels before the tile so that every scalar
     // offset is non-negative (what lies before the tensor is never addressed: those rows are invalid).
     const int hw3 = p.H * p.W;
@@ -514,9 +529,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       int h = rem / p.W;
       int w = rem - h * p.W;
 #pragma unroll
-      for (int c = 0; c < 5; ++c) {
+      for (int c = 0; c <= NCH; ++c) {
         const int m = mp0 + c * 64;
-        const bool ok = m >= 0 && m < p.M && (c < 4 || tid < 16);
+        const bool ok = m >= 0 && m < p.M && (c < NCH || tid < 16);
         const unsigned bits = (h > 0 ? 1u : 0u) | 2u | (h < p.H - 1 ? 4u : 0u);
         am |= (ok ? bits : 0u) << (3 * c);
         w += step_w;
@@ -532,10 +547,30 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     auto issue_img = [&](auto c_, auto ib_, int dyi, unsigned soff) {          // chunk c of the super-tile at (dyi, soff)
       constexpr int c = decltype(c_)::value, ib = decltype(ib_)::value;
       const unsigned vo = ((am >> (3 * c + dyi)) & 1u) ? a_voff : DTP_OOB_OFF;
-      const int dst = c < 4 ? ib * IMG + c * 8192 + wave * 1024
-                            : (wave == 0 ? ib * IMG + 4 * 8192 : ZOFF + (wave - 1) * 1024);
+      const int dst = c < NCH ? ib * IMG + c * 8192 + wave * 1024
+                              : (wave == 0 ? ib * IMG + NCH * 8192 : ZOFF + (wave - 1) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)(smem + dst), 16, vo,
                                                soff + c * cstride, 0, 0);
+    };
+    auto issue_slot = [&](auto s_, auto ib_, int dyi, unsigned soff) {         // even-phase slot s of a super-tile
+      constexpr int sl = decltype(s_)::value;
+      using IC = std::integral_constant<int, 0>;
+      (void)sizeof(IC);
+      if constexpr (NCH == 4) {
+        if constexpr (sl == 0) { issue_img(std::integral_constant<int, 0>{}, ib_, dyi, soff); issue_img(std::integral_constant<int, 4>{}, ib_, dyi, soff); }
+        if constexpr (sl == 1) issue_img(std::integral_constant<int, 1>{}, ib_, dyi, soff);
+        if constexpr (sl == 2) issue_img(std::integral_constant<int, 2>{}, ib_, dyi, soff);
+        if constexpr (sl == 3) issue_img(std::integral_constant<int, 3>{}, ib_, dyi, soff);
+      } else {
+        if constexpr (sl == 0) {
+          issue_img(std::integral_constant<int, 0>{}, ib_, dyi, soff);
+          issue_img(std::integral_constant<int, 6>{}, ib_, dyi, soff);
+          issue_img(std::integral_constant<int, 1>{}, ib_, dyi, soff);
+        }
+        if constexpr (sl == 1) { issue_img(std::integral_constant<int, 2>{}, ib_, dyi, soff); issue_img(std::integral_constant<int, 3>{}, ib_, dyi, soff); }
+        if constexpr (sl == 2) issue_img(std::integral_constant<int, 4>{}, ib_, dyi, soff);
+        if constexpr (sl == 3) issue_img(std::integral_constant<int, 5>{}, ib_, dyi, soff);
+      }
     };
     // B half-tiles: LDS row rho = 64*j + srow <-> tile row ((rho>>5)<<6) + h*32 + (rho&31), as PIPE 2
     const __amdgpu_buffer_rsrc_t b_rs = make_rsrc(p.B + (long)n0 * p.ldb * 2, (long)(p.Ncols - n0) * p.ldb * 2);
@@ -563,18 +598,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       const int rr = frow + dxi;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
-        fb[dxi][ks] = lds0 + (wm * 128 + rr) * 128 + (((ks * 4 + fk) ^ ((rr >> 1) & 7)) << 4);
+        fb[dxi][ks] = lds0 + (wm * WR + rr) * 128 + (((ks * 4 + fk) ^ ((rr >> 1) & 7)) << 4);
     }
     const unsigned zb[2] = {lds0 + ZOFF, lds0 + ZOFF - IMG};       // + ib*IMG + immediate lands in the zero region
-    // ---- dx border masks: fragment f = 4h + i of this wave row = tile rows wm*128 + 16*f + frow.  A
+    // ---- dx border masks: fragment f = FH*h + i of this wave row = tile rows wm*WR + 16*f + frow.  A
     // fragment's 16 pixels are lanes 0..15 (lanes l, l+16, l+32, l+48 hold the same pixel), so a mask is a
     // 16-bit pattern: 16 patterns packed in 8 SGPRs, widened to a wave mask where they are used (SALU)
-    unsigned pm_m1[4], pm_p1[4];
+    unsigned pm_m1[FH], pm_p1[FH];
     {
       const int step16 = 16 % p.W;
-      int w = (m0 + wm * 128 + frow) % p.W;
+      int w = (m0 + wm * WR + frow) % p.W;
 #pragma unroll
-      for (int f = 0; f < 8; ++f) {
+      for (int f = 0; f < 2 * FH; ++f) {
         const unsigned b0 = (unsigned)__builtin_amdgcn_ballot_w64(w == 0) & 0xFFFFu;
         const unsigned b1 = (unsigned)__builtin_amdgcn_ballot_w64(w == p.W - 1) & 0xFFFFu;
         if (f & 1) { pm_m1[f >> 1] |= b0 << 16; pm_p1[f >> 1] |= b1 << 16; }
@@ -588,16 +623,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       const unsigned m32 = p16 | (p16 << 16);
       return ((unsigned long long)m32 << 32) | m32;
     };
-    bf16x8_t xa[2][4], b0f[2][2], b1f[2][2];
+    bf16x8_t xa[2][FH], b0f[2][2], b1f[2][2];
     typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_t;
 #define DTP3_SEL(dst, normal, zero, mask) asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(dst) : "v"(normal), "v"(zero), "s"(mask))
 #define DTP3_READ_A(h, ib, dxi)                                                                       \
   {                                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i) {  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < FH; ++i) { \
       unsigned a_ = fb[dxi][ks];                                                                      \
-      if ((dxi) == 0) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_m1[(4 * (h) + i) >> 1], 4 * (h) + i)); \
-      if ((dxi) == 2) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_p1[(4 * (h) + i) >> 1], 4 * (h) + i)); \
-      xa[ks][i] = *(lds_frag_t)(size_t)(a_ + ((ib) * IMG + (h) * 8192 + i * 2048));                   \
+      if ((dxi) == 0) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_m1[(FH * (h) + i) >> 1], FH * (h) + i)); \
+      if ((dxi) == 2) DTP3_SEL(a_, fb[dxi][ks], zb[ib], wave_mask(pm_p1[(FH * (h) + i) >> 1], FH * (h) + i)); \
+      xa[ks][i] = *(lds_frag_t)(size_t)(a_ + ((ib) * IMG + (h) * HS + i * 2048));                     \
     }                                                                                                 \
   }
 #define DTP3_READ_B(h, d, dst)                                                                        \
@@ -607,9 +642,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         dst[ks][j] = *(const bf16x8_t*)(s_ + j * 2048 + (ks ? foff1 : foff0));                        \
   }
 #define DTP3_MMA(mh, nh, bf)                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)      \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(mh) * 4 + i][(nh) * 2 + j] =                 \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], xa[ks][i], acc[(mh) * 4 + i][(nh) * 2 + j], 0, 0, 0);
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < FH; ++i)     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(mh) * FH + i][(nh) * 2 + j] =                \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], xa[ks][i], acc[(mh) * FH + i][(nh) * 2 + j], 0, 0, 0);
 #define DTP3_SYNC_IN(VM)                                      \
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");   \
   __builtin_amdgcn_s_barrier();                               \
@@ -631,10 +666,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     // DMA issue points:  q1: B1(T+1)   q2: image slot   q3: B0(T+2)   q4: image slot
     //   image slots of a super-tile (next image, buffer 1-ib): (j0,q2) chunk 0 + halo, (j0,q4) chunk 1,
     //   (j1,q2) chunk 2, (j1,q4) chunk 3, (j2,*) nothing.
-    // Counted waits (loads that may stay in flight behind the one the NEXT phase reads):
-    //   after q1: B1(T), issued at q1 of T-1   -> j0: 0+2+0+2 = 4,  j1: 2+2+1+2 = 7,  j2: 1+2+1+2 = 6
-    //   after q4: B0(T+1), issued at q3 of T-1 -> j0: 0+2+2+2+1 = 7, j1: 1+2+1+2+1 = 7,
-    //             j2: the whole next image as well (its last chunk went out at q4 of T-1): 2+2 = 4
+    // Counted waits (loads that may stay in flight behind the one the NEXT phase reads), with L_s = image
+    // loads of slot s and NB = loads of a B half-tile (256x256: L = 2 1 1 1 0 0, NB = 2 -> 4 7 6 / 7 7 4):
+    //   after q1: B1(T), issued at q1 of T-1:   the two slots of T-1 + 2 NB
+    //   after q4: B0(T+1), issued at q3 of T-1: slot (T-1,q4) + the two slots of T + 2 NB; after (j2,q4) the
+    //             whole next image as well (its last chunk went out at (j1,q4)): L4 + L5 + 2 NB
     //   q2, q3: the next phase reads nothing new (image rows are static within a super-tile)
 #define DTP3_TILE(j, ib, d, KB1, KB2, VQ1, VQ4, SLOT2, SLOT4)                                         \
       DTP3_READ_A(0, ib, j) DTP3_READ_B(0, d, b0f)                                     /* q1 */       \
@@ -649,23 +685,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       SLOT4                                                                            /* q4 */       \
       DTP3_SYNC_IN(VQ4); DTP3_MMA(1, 0, b0f) DTP3_SYNC_OUT();
     // one super-tile: kb = its weight column, kbn / sin / dyn = weight column, image offset, dy index of the NEXT one
+#define DTP3_SLOT(sl, ib, dyn, sin) issue_slot(std::integral_constant<int, sl>{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);
 #define DTP3_SUPER(ib, d0, kb, kbn, sin, dyn)                                                         \
-      DTP3_TILE(0, ib, d0, (kb) + c2, (kb) + 2 * c2, 4, 7,                                            \
-                issue_img(J0{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);                   \
-                issue_img(J4{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);,                  \
-                issue_img(J1{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);)                  \
-      DTP3_TILE(1, ib, 1 - (d0), (kb) + 2 * c2, (kbn), 7, 7,                                          \
-                issue_img(J2{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);,                  \
-                issue_img(J3{}, std::integral_constant<int, 1 - (ib)>{}, dyn, sin);)                  \
-      DTP3_TILE(2, ib, d0, (kbn), (kbn) + c2, 6, 4, , )
+      DTP3_TILE(0, ib, d0, (kb) + c2, (kb) + 2 * c2, VQ1_0, VQ4_0, DTP3_SLOT(0, ib, dyn, sin), DTP3_SLOT(1, ib, dyn, sin)) \
+      DTP3_TILE(1, ib, 1 - (d0), (kb) + 2 * c2, (kbn), VQ1_1, VQ4_1, DTP3_SLOT(2, ib, dyn, sin), DTP3_SLOT(3, ib, dyn, sin)) \
+      DTP3_TILE(2, ib, d0, (kbn), (kbn) + c2, VQ1_2, VQ4_2, , )
 
     // prologue (issue order = the steady state's: B0(0); image 0; B1(0); B0(1))
     issue_B3(J0{}, J0{}, 0u);
-    issue_img(J0{}, J0{}, 0, 0u);
-    issue_img(J4{}, J0{}, 0, 0u);
-    issue_img(J1{}, J0{}, 0, 0u);
-    issue_img(J2{}, J0{}, 0, 0u);
-    issue_img(J3{}, J0{}, 0, 0u);
+    issue_slot(J0{}, J0{}, 0, 0u);
+    issue_slot(J1{}, J0{}, 0, 0u);
+    issue_slot(J2{}, J0{}, 0, 0u);
+    issue_slot(J3{}, J0{}, 0, 0u);
     issue_B3(J1{}, J0{}, 0u);
     issue_B3(J0{}, J1{}, c2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
@@ -688,6 +719,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     if (grp == 0) __builtin_amdgcn_s_barrier();    // pair the stagger barrier of the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain (dummy) DMA before the C image reuses LDS
 #undef DTP3_SUPER
+#undef DTP3_SLOT
 #undef DTP3_TILE
 #undef DTP3_SYNC_OUT
 #undef DTP3_SYNC_IN
@@ -1042,7 +1074,8 @@ static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Ncols + BN - 1) / BN;
-  constexpr int lds = PIPE == 3 ? 2 * 264 * 128 + 4 * (WGN * 4096) + (8192 + 3 * 2048 + 512) : 2 * (BM + BN) * 128;
+  constexpr int lds = PIPE == 3 ? 2 * (BM + 8) * 128 + 4 * (WGN * 4096) + ((2 * (BM / WGM / 32) - 1) * 2048 + 512)
+                                : 2 * (BM + BN) * 128;
   static bool attr_set = false;
   auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE, FP8>;
   if (!attr_set) {
@@ -1125,6 +1158,10 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 18:        // 8-phase over one staged activation image per tap row (3x3 only, C % 128 == 0, no split-K)
       if (!t9 || nsplit != 1 || (C & 127)) return -22;
       rc = launch_cfg<256, 256, 2, 4, true, 3>(p, nsplit, stream);
+      break;
+    case 19:        // the same schedule as a 384x128 tile (4x2 waves of 96x64) for outputs of <= 128 channels
+      if (!t9 || nsplit != 1 || (C & 127)) return -22;
+      rc = launch_cfg<384, 128, 4, 2, true, 3>(p, nsplit, stream);
       break;
     default: return -16;
   }

@@ -20,6 +20,7 @@ N_CU = 256
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
                18: (256, 256),   # cfg 16's schedule over ONE staged activation image per tap row (3x3, C % 128 == 0)
+               19: (384, 128),   # the same for outputs of <= 128 channels (4x2 waves of 96x64)
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
 WGRAD_TILES = {2: (128, 64), 3: (64, 128), 4: (64, 64),    # wgrad.hip: small-tile fallbacks (narrow outputs)
                8: (256, 256), 9: (128, 128)}   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
@@ -168,6 +169,7 @@ fuse_colsum = True      # tests flip this to compare against the stand-alone col
 two_pass_c128 = _os.environ.get("DTP_DGRAD_TWO_PASS", "0") == "1"
 igemm_512 = _os.environ.get("DTP_IGEMM_512", "1") != "0"              # A/B switch: 512x128 8-phase tile
 igemm_shared_a = _os.environ.get("DTP_IGEMM_SHARED_A", "1") != "0"    # A/B switch: one staged activation image per tap row (cfg 18)
+igemm_shared_a_n128 = _os.environ.get("DTP_IGEMM_SHARED_A_N128", "1") != "0"   # A/B switch: ... for <= 128 output channels (cfg 19)
 relu_bitmask = _os.environ.get("DTP_RELU_BITMASK", "1") != "0"        # A/B switch: 1-bit ReLU masks for dgrad
 
 
@@ -205,6 +207,11 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
         cfg = 18
     elif cfg == 18 and not shared_ok:
         cfg = 16
+    elif (cfg in (17, 3) and 64 < Ncols <= 128 and shared_ok and igemm_shared_a and igemm_shared_a_n128
+          and "igemm" not in _overrides and _cdiv(M, 384) >= 4 * N_CU):
+        cfg = 19          # 384x128 tiles over the shared image: conv2_2 forward / data gradient, conv3_1's data gradient
+    elif cfg == 19 and not shared_ok:
+        cfg = 3
     if fp8:      # fp8 operands are instantiated for the 2-stage 256x128 / 128x128 / 128x64 tiles
         cfg = {16: 1, 0: 1, 8: 1, 9: 1, 1: 1, 11: 3, 3: 3, 2: 4, 10: 4, 12: 4, 4: 4}[cfg]
         if IGEMM_TILES[cfg][0] * IGEMM_TILES[cfg][1] < 256 * 256 and nsplit == 1:
