@@ -39,6 +39,7 @@ struct IgemmParams {
   const char* bn_y;       // optional bf16 [M][ldo] (with colsum_sq): this output is dz, the gradient of
   const float* bn_scale;  //   z = relu(y*scale + shift) (a training-mode BatchNorm + ReLU); the partial rows become
   const float* bn_shift;  //   (sum dyh, sum dyh*y) with dyh = dz * (y*scale + shift > 0)   [no mask when bn_scale is null]
+  uint32_t* pool_codes;   // POOL kernels: `out` is the 2x2-max-pooled output [M/4][ldo], this the 4-bit codes [M/4][Ncols/8]
                           //   — the two reductions of the BatchNorm backward, which then skips its pass over (dz, y)
   int colsum_sq;          // colsum_part is [tiles_m][2][Ncols]: sums AND sums of squares — the batch
                           // statistics of a BatchNorm that follows this convolution (bn.hip partial layout)
@@ -83,8 +84,9 @@ DTP_DEVINL f32x4_t mma16(const bf16x8_t& w, const bf16x8_t& x, f32x4_t c) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false, bool POOL = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmParams p) {
+  static_assert(!POOL || PIPE == 3, "the fused max-pool rides on the shared-image schedule");
   static_assert(!FP8 || (PIPE == 0 && !TAPS9), "fp8 operands: plain GEMM, 2-stage loop only");
   static_assert(PIPE != 3 || TAPS9, "shared-image schedule is a 3x3 convolution schedule");
   constexpr int ES = FP8 ? 1 : 2;     // operand element size; a K-step is always 128 bytes per row
@@ -520,10 +522,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     // Image row r = 64c + srow (c < NCH; c == NCH: halo rows BM, BM + 1 = lanes 0..15 of wave 0) holds the
     // pixel m0 - 1 + r + dy*W; the descriptor starts W + 1 pixels before the tile so that every scalar
     // offset is non-negative (what lies before the tensor is never addressed: those rows are invalid).
+    // POOL (conv + ReLU + 2x2 max-pool in one kernel): output rows are enumerated (n, h/2, w, h&1) —
+    // m = ((n*(H/2) + h/2)*W + w)*2 + (h&1) — so a pooling window is four CONSECUTIVE tile rows
+    // (4k: (h, w), 4k+1: (h+1, w), 4k+2: (h, w+1), 4k+3: (h+1, w+1)) and never straddles a tile, whatever
+    // W is, while the dx taps stay a uniform shift of the staged image: TWO rows instead of one.  The
+    // pooled pixels of a tile are consecutive rows of the pooled NHWC tensor (m / 4).  The tensors
+    // themselves keep their layout: only the row -> pixel map of the loaders and the epilogue changes.
+    constexpr int DXR = POOL ? 2 : 1;         // image rows per dx step = halo rows on either side
     const int hw3 = p.H * p.W;
-    const int mp0 = m0 - 1 + srow;            // output pixel whose dx = 0 tap reads image row srow
+    const int mp0 = m0 - DXR + srow;          // output row whose dx = 0 tap reads image row srow
     unsigned am = 0;                          // 3 bits per chunk: row valid for dy = -1, 0, +1
-    {
+    unsigned kpack = 0;                       // POOL: 4 bits per chunk: image-row wraps since chunk 0
+    long a_first;                             // descriptor base, bytes from p.A (may lie before the tensor)
+    unsigned a_voff;
+    if constexpr (!POOL) {
       const int step_h = 64 / p.W, step_w = 64 - step_h * p.W;
       const int rem = (mp0 + hw3) % hw3;       // mp0 >= -1: pixel -1 walks on like the last pixel of an image
       int h = rem / p.W;
@@ -539,14 +551,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         if (w >= p.W) { w -= p.W; ++h; }
         while (h >= p.H) h -= p.H;
       }
+      a_first = (long)(m0 - 1 - p.W) * p.C * 2;
+      a_voff = (unsigned)((srow * p.C + lch * 8) * 2);
+    } else {
+      const int H2 = p.H >> 1;
+      const int r = mp0 & 1;                           // row of the pair (two's complement: -1 -> 1, -2 -> 0)
+      const int qs = (mp0 >> 1) + H2 * p.W;            // (w, pair) index, shifted by one image: >= 0
+      const int gs = qs / p.W;
+      int w = qs - gs * p.W;
+      int hp = gs % H2;
+      const int pix0 = (2 * (gs - H2) + r) * p.W + w;  // this lane's chunk-0 pixel in the tensor's own (n, h, w) order
+      // wave-uniform: first pixel the tile's dy = 0 taps can touch
+      const int qf = ((m0 - DXR) >> 1) + H2 * p.W;
+      const int gf = qf / p.W;
+      const int base_pix = 2 * (gf - H2) * p.W + (qf - gf * p.W);
+      const int step_g = 32 / p.W, step_w = 32 - step_g * p.W;
+      int kacc = 0;
+#pragma unroll
+      for (int c = 0; c <= NCH; ++c) {
+        const int m = mp0 + c * 64;
+        const int h = 2 * hp + r;
+        const bool ok = m >= 0 && m < p.M && (c < NCH || tid < 32);
+        const unsigned bits = (h > 0 ? 1u : 0u) | 2u | (h < p.H - 1 ? 4u : 0u);
+        am |= (ok ? bits : 0u) << (3 * c);
+        kpack |= (unsigned)(kacc & 15) << (4 * c);
+        int inc = step_g;
+        w += step_w;
+        if (w >= p.W) { w -= p.W; ++inc; }
+        hp += inc;
+        while (hp >= H2) hp -= H2;
+        kacc += inc;
+      }
+      a_first = (long)(base_pix - p.W) * p.C * 2;             // the dy = -1 taps read one image row earlier
+      a_voff = (unsigned)(((pix0 - base_pix) * p.C + lch * 8) * 2);
     }
-    const long a_first = (long)(m0 - 1 - p.W) * p.C * 2;                       // may lie before the tensor
     const __amdgpu_buffer_rsrc_t a_rs = make_rsrc(p.A + a_first, (long)p.M * p.C * 2 - a_first);
-    const unsigned a_voff = (unsigned)((srow * p.C + lch * 8) * 2);
-    const unsigned cstride = (unsigned)(64 * p.C * 2);                         // bytes between two chunks' rows
+    // bytes between two chunks' rows: 64 pixels, or (POOL) 32 pixel columns + the image rows wrapped (per lane)
+    const unsigned cstride = (unsigned)((POOL ? 32 : 64) * p.C * 2);
+    const unsigned wrap_bytes = (unsigned)(p.W * p.C * 2);
     auto issue_img = [&](auto c_, auto ib_, int dyi, unsigned soff) {          // chunk c of the super-tile at (dyi, soff)
       constexpr int c = decltype(c_)::value, ib = decltype(ib_)::value;
-      const unsigned vo = ((am >> (3 * c + dyi)) & 1u) ? a_voff : DTP_OOB_OFF;
+      unsigned vo = a_voff;
+      if constexpr (POOL) vo += ((kpack >> (4 * c)) & 15u) * wrap_bytes;
+      vo = ((am >> (3 * c + dyi)) & 1u) ? vo : DTP_OOB_OFF;
       const int dst = c < NCH ? ib * IMG + c * 8192 + wave * 1024
                               : (wave == 0 ? ib * IMG + NCH * 8192 : ZOFF + (wave - 1) * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)(smem + dst), 16, vo,
@@ -595,7 +642,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     unsigned fb[3][2];
 #pragma unroll
     for (int dxi = 0; dxi < 3; ++dxi) {
-      const int rr = frow + dxi;
+      const int rr = frow + DXR * dxi;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         fb[dxi][ks] = lds0 + (wm * WR + rr) * 128 + (((ks * 4 + fk) ^ ((rr >> 1) & 7)) << 4);
@@ -606,8 +653,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     // 16-bit pattern: 16 patterns packed in 8 SGPRs, widened to a wave mask where they are used (SALU)
     unsigned pm_m1[FH], pm_p1[FH];
     {
-      const int step16 = 16 % p.W;
-      int w = (m0 + wm * WR + frow) % p.W;
+      // (POOL: a tile row is half a pixel column step: 16 rows = 8 columns)
+      const int step16 = (POOL ? 8 : 16) % p.W;
+      int w = (POOL ? (m0 + wm * WR + frow) >> 1 : m0 + wm * WR + frow) % p.W;
 #pragma unroll
       for (int f = 0; f < 2 * FH; ++f) {
         const unsigned b0 = (unsigned)__builtin_amdgcn_ballot_w64(w == 0) & 0xFFFFu;
@@ -896,6 +944,53 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   __builtin_amdgcn_s_barrier();   // C image complete
   __builtin_amdgcn_sched_barrier(0);
   DTP_STAMP(6)
+  if constexpr (POOL) {
+    // 2x2 max-pool of the (bias + ReLU, bf16) C image: window k = tile rows 4k (h, w), 4k+2 (h, w+1),
+    // 4k+1 (h+1, w), 4k+3 (h+1, w+1); same 4-bit codes {bit 2: max > 0, bits 1:0: FIRST maximum in that
+    // order} as maxpool2x2_fwd_kernel (pool.hip), so the pool backward is the existing one.  A thread
+    // owns one 16-byte channel chunk and walks the windows: pooled rows go out as coalesced 16-byte
+    // stores, the full-resolution activation never leaves the CU.
+    constexpr int CPRp = BN / 8, NW = BM / 4;
+    static_assert(T % CPRp == 0 && (NW * CPRp) % T == 0, "pooled store geometry");
+    const int qq = tid % CPRp;
+    const int nq = n0 + qq * 8;
+    const int wins_valid = ((p.M - m0) < BM ? (p.M - m0) : BM) >> 2;
+    const long win0 = (long)m0 >> 2;
+    const int cvn = p.Ncols >> 3;
+#pragma unroll
+    for (int k = tid / CPRp; k < NW; k += T / CPRp) {
+      u32x4_t v[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int pl = 4 * k + r4;
+        v[r4] = *(const u32x4_t*)(smem + pl * (BN * 2) + ((qq ^ (pl & 7)) << 4));
+      }
+      u32x4_t o;
+      uint32_t code = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const float fa = hf ? __uint_as_float(v[0][e] & 0xFFFF0000u) : __uint_as_float(v[0][e] << 16);
+          const float fb = hf ? __uint_as_float(v[2][e] & 0xFFFF0000u) : __uint_as_float(v[2][e] << 16);
+          const float fc = hf ? __uint_as_float(v[1][e] & 0xFFFF0000u) : __uint_as_float(v[1][e] << 16);
+          const float fd = hf ? __uint_as_float(v[3][e] & 0xFFFF0000u) : __uint_as_float(v[3][e] << 16);
+          uint32_t arg = 0; float mx = fa;
+          if (fb > mx) { mx = fb; arg = 1; }
+          if (fc > mx) { mx = fc; arg = 2; }
+          if (fd > mx) { mx = fd; arg = 3; }
+          code |= (arg | (mx > 0.f ? 4u : 0u)) << (4 * (2 * e + hf));
+          const uint32_t bits = __float_as_uint(mx);          // exact: the inputs are bf16
+          if (hf) o[e] |= bits & 0xFFFF0000u; else o[e] = bits >> 16;
+        }
+      }
+      if (k < wins_valid && nq < p.Ncols) {
+        *(u32x4_t*)(p.out + ((win0 + k) * p.ldo + nq) * 2) = o;
+        p.pool_codes[(win0 + k) * cvn + (nq >> 3)] = code;
+      }
+    }
+    return;
+  }
   {
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float cq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1069,7 +1164,7 @@ __global__ void igemm_splitk_reduce_kernel(const float* __restrict__ partial, in
 }
 
 // -------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false>
+template <int BM, int BN, int WGM, int WGN, bool TAPS9, int PIPE, bool FP8 = false, bool POOL = false>
 static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   IgemmParams p = p0;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -1077,7 +1172,7 @@ static int launch_cfg(const IgemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int lds = PIPE == 3 ? 2 * (BM + 8) * 128 + 4 * (WGN * 4096) + ((2 * (BM / WGM / 32) - 1) * 2048 + 512)
                                 : 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE, FP8>;
+  auto kern = igemm_nt_kernel<BM, BN, WGM, WGN, TAPS9, PIPE, FP8, POOL>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -2;
@@ -1095,7 +1190,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
                             const float* dq_a, const float* dq_b, int colsum_sq, const void* bn_y,
-                            const float* bn_scale, const float* bn_shift, int nsplit, int cfg, hipStream_t stream) {
+                            const float* bn_scale, const float* bn_shift, void* pool_codes, int nsplit, int cfg,
+                            hipStream_t stream) {
   // fp8 != 0: 8-bit operands, A [M][lda] (fp8 == 1: OCP e4m3, fp8 == 2: e5m2), B [Ncols][ldb] e4m3, bytes; K = C a multiple of 128
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
   if (fp8 && (taps != 1 || (lda & 15) || (ldb & 15))) return -18;
@@ -1109,6 +1205,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.colsum_part = colsum_part;
   p.colsum_sq = colsum_part ? colsum_sq : 0;
   p.bn_y = (const char*)bn_y; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
+  p.pool_codes = (uint32_t*)pool_codes;
+  if ((cfg == 20 || cfg == 21) != (pool_codes != nullptr)) return -23;      // pooled output <-> pooling kernel
   if (bn_y && (!colsum_part || !colsum_sq || out_fp32 || (bn_scale && !bn_shift))) return -21;
   p.mask_bits = (const unsigned char*)mask_bits; p.bits_out = (unsigned char*)bits_out;
   p.M = M; p.Ncols = Ncols; p.C = C; p.H = H; p.W = W; p.lda = lda; p.ldb = ldb; p.ldo = ldo;
@@ -1162,6 +1260,13 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 19:        // the same schedule as a 384x128 tile (4x2 waves of 96x64) for outputs of <= 128 channels
       if (!t9 || nsplit != 1 || (C & 127)) return -22;
       rc = launch_cfg<384, 128, 4, 2, true, 3>(p, nsplit, stream);
+      break;
+    case 20: case 21:   // cfg 18 / 19 + ReLU + 2x2 max-pool in the epilogue: `out` is the POOLED tensor [M/4][ldo]
+      if (!t9 || nsplit != 1 || (C & 127) || !relu || out_fp32 || (H & 1) || (W & 1) || W < 14 || mask_src || mask_bits ||
+          bits_out || colsum_part || bn_y)
+        return -24;
+      rc = cfg == 20 ? launch_cfg<256, 256, 2, 4, true, 3, false, true>(p, nsplit, stream)
+                     : launch_cfg<384, 128, 4, 2, true, 3, false, true>(p, nsplit, stream);
       break;
     default: return -16;
   }

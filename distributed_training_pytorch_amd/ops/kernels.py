@@ -21,6 +21,7 @@ N_CU = 256
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
                18: (256, 256),   # cfg 16's schedule over ONE staged activation image per tap row (3x3, C % 128 == 0)
                19: (384, 128),   # the same for outputs of <= 128 channels (4x2 waves of 96x64)
+               20: (256, 256), 21: (384, 128),   # cfg 18 / 19 + ReLU + 2x2 max-pool in the epilogue (pooled output)
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
 WGRAD_TILES = {2: (128, 64), 3: (64, 128), 4: (64, 64),    # wgrad.hip: small-tile fallbacks (narrow outputs)
                8: (256, 256), 9: (128, 128)}   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
@@ -163,6 +164,7 @@ bn_stats_slot = _ColsumSlot()
 bn_bwd_slot = _ColsumSlot()
 fuse_bn_stats = _os.environ.get("DTP_FUSE_BN_STATS", "1") != "0"      # A/B switch
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
+fuse_igemm_pool = _os.environ.get("DTP_FUSE_IGEMM_POOL", "1") != "0"  # A/B switch: ... for the implicit-GEMM layers (blocks 2-5)
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
 # conv2_1 dgrad as 2 conv_c64 passes: measured 640 vs 662 TF/s for the implicit GEMM at batch 256 and
 # no end-to-end difference (bench/bench_dgrad_c128.py, profiles/18_*): opt-in only
@@ -196,9 +198,18 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
            mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
-           bits_out=None, fp8_mode=1, want_bn_stats=False, bn_bwd_src=None):
+           bits_out=None, fp8_mode=1, want_bn_stats=False, bn_bwd_src=None, pool_codes=None):
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
+    if pool_codes is not None:
+        # conv + ReLU + 2x2 max-pool in one kernel: `out` is the pooled tensor (csrc/igemm.hip POOL)
+        cfg = 20 if Ncols > 128 else 21
+        rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), None, None, None, ptr(out), None, None,
+                                     ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo, 0, 1,
+                                     1.0, 0.0, 0, None, 0, None, None, 0, None, None, None, ptr(pool_codes), 1, cfg,
+                                     stream())
+        check(rc, "igemm_nt (conv + relu + pool)")
+        return out
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
     # cfg 18 = cfg 16 with the three dx taps of a filter row reading one staged activation image
     # (csrc/igemm.hip PIPE 3: a third of the A-operand LDS-DMA / L2 reads; same sums, bit for bit)
@@ -257,7 +268,7 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  ptr(seed_ptr), int(fp8_mode) if fp8 else 0, ptr(fp8_scales[0]) if fp8 else None,
                                  ptr(fp8_scales[1]) if fp8 else None, colsum_sq, ptr(bn_y), ptr(bn_sc), ptr(bn_sh),
-                                 nsplit, cfg, stream())
+                                 None, nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
@@ -319,10 +330,22 @@ def conv3x3_fprop(x, w, bias=None, relu=True, out=None, want_bits=False, want_bn
     return (out, bits) if want_bits else out
 
 
-def conv_pool_fusable(C, Cout, H, W):
-    """Shapes for which conv3x3 + ReLU + 2x2 max-pool run as ONE kernel (conv_c64 POOL epilogue)."""
-    return (fuse_conv_pool and C == 64 and Cout in (64, 128) and H % 2 == 0 and W % 2 == 0
-            and "igemm" not in _overrides)
+def conv_pool_fusable(C, Cout, H, W, N=None):
+    """Shapes for which conv3x3 + ReLU + 2x2 max-pool run as ONE kernel: 64 reduction channels
+    (conv_c64's POOL epilogue: block 1), or the shared-image implicit GEMM with the pooled epilogue
+    (cfg 20 / 21: reduction channels a multiple of 128, > 64 outputs, even H, even W >= 14 — the block
+    ends of VGG16's blocks 2-5).  ``N`` (batch): the implicit-GEMM form needs enough tiles to fill the
+    CUs (small batches keep the split-K capable unfused kernels)."""
+    if not fuse_conv_pool or H % 2 or W % 2 or "igemm" in _overrides:
+        return False
+    if C == 64 and Cout in (64, 128):
+        return True
+    if not (fuse_igemm_pool and igemm_shared_a and C % 128 == 0 and Cout > 64 and Cout % 8 == 0 and W >= 14):
+        return False
+    if N is None:
+        return True
+    bm, bn = IGEMM_TILES[20 if Cout > 128 else 21]
+    return _cdiv(N * H * W, bm) * _cdiv(Cout, bn) >= N_CU // 2
 
 
 def conv3x3_relu_pool_fprop(x, w, bias):
@@ -338,7 +361,11 @@ def conv3x3_relu_pool_fprop(x, w, bias):
         _need(bias, torch.float32, "bias")
     y = torch.empty((N, H // 2, W // 2, Cout), dtype=BF16, device=x.device)
     codes = torch.empty((N, H // 2, W // 2, Cout // 8), dtype=torch.int32, device=x.device)
-    _conv_c64(x, w, bias, None, y, N, H, W, Cout, True, 1.0, codes=codes)
+    if C == 64:
+        _conv_c64(x, w, bias, None, y, N, H, W, Cout, True, 1.0, codes=codes)
+    else:
+        _igemm(x, w, bias, None, y, N * H * W, Cout, C, 9, H, W, C, 9 * C, Cout, False, True, 1.0, 0.0, 0,
+               pool_codes=codes)
     return y, codes
 
 

@@ -242,7 +242,7 @@ def conv_relu_pool(conv, x):
     if (not x.is_cuda or not isinstance(conv, Conv3x3) or not conv.relu or not conv.grad_premasked
             or conv.bias is None or x.dim() != 4):
         return None
-    if not K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2]):
+    if not K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2], N=x.shape[0]):
         return None
     return _Conv3x3ReluPoolFn.apply(x, conv.weight, conv.bias, conv)
 
@@ -661,6 +661,7 @@ def bn_relu_pool(bn, y):
     if not (FUSE_BN_POOL and bn.training and bn.relu and y.is_cuda and K.bn_pool_fusable(y)):
         return None
     bn.num_batches_tracked += 1
+    bn.stats_epoch += 1             # the kernels move the running statistics through raw pointers
     return _BatchNormReLUPoolFn.apply(y, bn.weight, bn.bias, bn)
 
 
@@ -680,6 +681,10 @@ class BatchNormReLU(FusedLayer):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        # bumped whenever the running statistics change behind torch's back (the kernels and the native
+        # RCCL broadcast write them through raw pointers: tensor._version does not move) — part of the
+        # key of the folded-weights cache of conv_bn_relu_folded
+        self.stats_epoch = 0
 
     def eval_coeffs(self):
         """(scale, shift) of the eval-mode affine map, from the fp32 master parameters."""
@@ -697,6 +702,7 @@ class BatchNormReLU(FusedLayer):
             return F.relu(y) if self.relu else y
         if self.training:
             self.num_batches_tracked += 1
+            self.stats_epoch += 1
             z = _BatchNormReLUFn.apply(x, self.weight, self.bias, self)
             src = self.__dict__.pop("_bn_src_tmp", None)
             if src is not None:
@@ -720,7 +726,7 @@ def conv_bn_relu_folded(conv, bn, x, pool=False):
     ``pool``: the block's 2x2 max-pool follows; where the shapes allow it (64 input channels) it
     joins the same kernel and ``(y, True)`` is returned, else ``(y, False)`` with y un-pooled."""
     arena = _arena_of(conv)
-    key = (arena.lp_epoch, bn.running_mean._version, bn.running_var._version)
+    key = (arena.lp_epoch, bn.stats_epoch, bn.running_mean._version, bn.running_var._version)
     cached = conv.__dict__.get("_bnfold")
     if cached is None or cached[0] != key:
         scale, shift = bn.eval_coeffs()
@@ -737,7 +743,8 @@ def conv_bn_relu_folded(conv, bn, x, pool=False):
         y = K.conv1_fprop(x, wf, bf, bn.relu, conv.in_scale, conv.in_mean, conv.in_inv_std)
         return (y, False) if pool else y
     if pool:
-        if bn.relu and x.dim() == 4 and K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2]):
+        if bn.relu and x.dim() == 4 and K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2],
+                                                            N=x.shape[0]):
             return K.conv3x3_relu_pool_fprop(x, wf, bf)[0], True
         return K.conv3x3_fprop(x, wf, bf, relu=bn.relu), False
     return K.conv3x3_fprop(x, wf, bf, relu=bn.relu)

@@ -99,6 +99,9 @@ class DataParallel(nn.Module):
                     and getattr(b, "_dtp_sync", True)]
             if bufs:
                 self.reducer.broadcast_parameters(bufs)
+                for m in self.module.modules():          # caches keyed on the statistics (folded conv+BN weights)
+                    if hasattr(m, "stats_epoch"):
+                        m.stats_epoch += 1
         self._buffers_dirty = False
 
     def train(self, mode=True):

@@ -645,6 +645,34 @@ def test_fused_conv_relu_pool_matches_separate_kernels(shape):
     assert torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize("shape", [(8, 112, 112, 128, 128), (6, 56, 56, 256, 256), (9, 28, 28, 512, 512), (40, 14, 14, 512, 512),
+                                   (3, 30, 26, 128, 256), (5, 16, 14, 128, 72), (2, 18, 44, 256, 320), (70, 4, 14, 128, 128)])
+def test_fused_conv_relu_pool_in_the_implicit_gemm(shape):
+    """cfg 20 / 21 (csrc/igemm.hip PIPE 3 + POOL): conv3x3 + bias + ReLU + 2x2 max-pool as ONE kernel for
+    the block ends of VGG16's blocks 2-5 (and odd shapes: M / N tails, H != W, widths from 14 to 112,
+    images smaller than a tile).  Output rows are enumerated (n, h/2, w, h&1) inside the kernel; pooled
+    activations AND the 4-bit (first argmax, max > 0) codes must equal conv3x3_fprop + maxpool2x2_fwd
+    bit for bit, so the existing pool backward applies unchanged."""
+    k = _k()
+    N, H, W, C, Co = shape
+    torch.manual_seed(71)
+    x = _rand(N, H, W, C)
+    w = _rand(Co, 9 * C, scale=(2.0 / (9 * C)) ** 0.5)
+    b = torch.randn(Co, device="cuda") * 0.1
+    assert k.conv_pool_fusable(C, Co, H, W)
+    y_full = _with_cfg(k, 3, lambda: k.conv3x3_fprop(x, w, b, relu=True))
+    y_ref, codes_ref = k.maxpool2x2_fwd(y_full, want_idx=True)
+    for _ in range(2):
+        y, codes = k.conv3x3_relu_pool_fprop(x, w, b)
+        assert tuple(y.shape) == (N, H // 2, W // 2, Co)
+        assert torch.equal(y, y_ref), "pooled output: max diff %g" % (y.float() - y_ref.float()).abs().max().item()
+        assert torch.equal(codes, codes_ref)
+    dyp = _rand(*y.shape)
+    dx_ref = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes_ref, in_shape=tuple(y_full.shape))
+    dx = k.maxpool2x2_bwd(None, dyp, relu_mask=True, idx=codes, in_shape=tuple(y_full.shape))
+    assert torch.equal(dx, dx_ref)
+
+
 @pytest.mark.parametrize("shape", [(2, 20, 12, 128, 256), (3, 9, 11, 64, 128), (2, 14, 14, 256, 192), (1, 30, 34, 64, 64)])
 def test_relu_bitmask_roundtrip(shape):
     """conv3x3_fprop(want_bits) packs (y > 0) one bit per element (igemm and conv_c64 epilogues); the
