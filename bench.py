@@ -70,6 +70,11 @@ def parse_args(argv=None):
                          "steps device-resident batches) instead of cycling through 2: the net cannot memorise, "
                          "so activation / gradient sparsity — which the power-limited matrix kernels are "
                          "sensitive to — stays that of a freshly initialised net")
+    ap.add_argument("--hip-graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture zero_grad + forward + loss + backward + optimizer into ONE hipGraph launch "
+                         "(engine/graph.py).  auto: single-GPU runs at per-GPU batch <= 32, where the ~140 launches "
+                         "of a step cost the host more than the GPU needs to run them (the reference's own "
+                         "regime: 4 images per GPU, main.py:15 / run.sh:10)")
     ap.add_argument("--no-bucket-optimizer", action="store_true",
                     help="N > 1: run the fused SGD as one pass after the last gradient bucket instead of per "
                          "bucket behind its all-reduce (the default; parallel/reducer.py)")
@@ -166,7 +171,19 @@ def main(argv=None):
         data_desc = "synthetic (device-resident f32 NCHW batches, %s, random-init weights)" % (
             "a fresh batch every step" if args.fresh_data else "2 distinct batches cycled")
 
+    use_graph = args.hip_graph == "on" or (args.hip_graph == "auto" and world == 1 and args.batch_per_gpu <= 32)
+    use_graph = use_graph and on_gpu and args.grad_accum == 1 and args.data == "device"
+    graphed = None
+    if use_graph:
+        from distributed_training_pytorch_amd.engine.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(dp, crit, opt, warmup=2)
+        if not graphed.enabled:
+            graphed = None
+
     def step():
+        if graphed is not None:                 # the same work as below, replayed as one graph launch
+            x, y = next(data)
+            return graphed(x, y)
         opt.zero_grad()
         for k in range(args.grad_accum):
             x, y = next(data)
@@ -277,6 +294,7 @@ def main(argv=None):
             "dtype": "bf16" if on_gpu else "fp32 (CPU rehearsal on the reference ops, not a benchmark)",
             "data": data_desc,
             "final_loss": final_loss,
+            "hip_graph": graphed is not None and graphed.replays > 0,
             "max_memory_reserved_gb": (torch.cuda.max_memory_reserved(dev) / 2 ** 30) if on_gpu else 0.0,
             "allreduce_exposed_ms_per_step": exposed,     # compute stream idle waiting for gradient buckets (rank 0)
             "data_wait_ms_per_step": data_wait,           # host blocked on the input ring (rank 0)

@@ -870,6 +870,9 @@ def cast_f32_bf16(src, dst):
 # head start (microseconds) for wgrad_c64's persistent grid before the data gradient of the same layer
 # is dispatched on the other stream (csrc/eltwise.hip stream_delay_kernel); 0 = off
 wgrad_head_start_us = float(_os.environ.get("DTP_WGRAD_HEAD_START_US", "20"))
+# ... only where the kernels are long enough for grid residency to matter: at per-GPU batch 4 the two 20 us
+# delays were 44 us of a 2.3 ms step (profiles/73_*) for kernels that take 30 us themselves
+WGRAD_HEAD_START_MIN_ELEMS = 1 << 25
 
 
 def wgrad_is_persistent(C, Co):

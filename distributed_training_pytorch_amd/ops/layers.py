@@ -170,7 +170,7 @@ class _Conv3x3Fn(torch.autograd.Function):
             # tiles (conv5: 196 tiles on 256 CUs) is filled by the other's workgroups
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-            if K.wgrad_is_persistent(x.shape[3], Co):
+            if K.wgrad_is_persistent(x.shape[3], Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
                 K.stream_delay(K.wgrad_head_start_us)     # the persistent grid must be resident first
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
@@ -218,7 +218,7 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         if side is not None:
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-            if K.wgrad_is_persistent(Ci, Co):
+            if K.wgrad_is_persistent(Ci, Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
                 K.stream_delay(K.wgrad_head_start_us)
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))

@@ -263,6 +263,7 @@ class BucketedReducer(object):
         self.buckets = []
         self._param_buckets = {}
         self.sharded = False
+        self.local_overlap = False
         self.fused_update = False    # an optimizer runs inside the reducer (sharded or per-bucket replicated)
         self.opt = None
         if shard_optimizer is not None and bucket_optimizer is not None:
@@ -279,6 +280,14 @@ class BucketedReducer(object):
             # incl. the C++ scheduler's optimizer launches on the communication stream)
             self.fused_update = self.world > 1 or (bucket_optimizer is not None
                                                    and os.environ.get("DTP_BUCKET_OPT_FORCE") == "1")
+            # world size 1 on a GPU: nothing to communicate, but the per-bucket placement still pays — each
+            # bucket's optimizer slice runs on a side stream the moment its gradients are final, under the
+            # rest of backward, instead of as one 134 M-element pass behind the last kernel (0.56 ms of a
+            # 2.3 ms step at per-GPU batch 4; inside a captured hipGraph step it is a parallel branch)
+            self.local_overlap = (self.world == 1 and bucket_optimizer is not None and on_gpu
+                                  and not self.fused_update and os.environ.get("DTP_LOCAL_BUCKET_OPT", "1") != "0")
+            self.fused_update = self.fused_update or self.local_overlap
+            self._opt_stream = None
             self.opt = in_reducer
         if flat_grad is not None:
             # arena mode: params' grads already are views of flat_grad at flat_offsets[i]; a bucket is
@@ -517,6 +526,17 @@ class BucketedReducer(object):
     def _launch_traced(self, b, buf):
         if self.fused_update:
             self._begin_pass()
+        if self.local_overlap:
+            # world 1: this bucket's update on the optimizer stream, ordered after everything queued so far
+            # (the kernels that wrote and read this bucket's gradients / weights); joined in _finalize
+            if self._opt_stream is None:
+                self._opt_stream = torch.cuda.Stream(device=buf.device)
+            self._opt_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._opt_stream):
+                self.opt.update_range(b.lo, b.hi, **self._pass)
+            b.work = None
+            self.stats["launched"] += 1
+            return
         if self.sharded:
             b.work = self.transport.reduce_scatter(buf)
             self.stats["launched"] += 1
@@ -580,7 +600,13 @@ class BucketedReducer(object):
                 self.opt.step_closed_by_reducer()
                 self._pass = None
             kw = self._begin_pass() if (self.fused_update and not self.sharded) else None
-            for b in (() if self.sharded else self.buckets):
+            if self.local_overlap:
+                if self._opt_stream is not None:
+                    torch.cuda.current_stream().wait_stream(self._opt_stream)
+                kw_done, kw = kw, None          # every bucket was updated on the optimizer stream already
+                self.opt.step_closed_by_reducer()
+                self._pass = None
+            for b in (() if (self.sharded or self.local_overlap) else self.buckets):
                 buf = b.comm_buf if b.comm_buf is not None else b.flat
                 self.transport.wait(b.work, buf)
                 if b.comm_buf is not None:

@@ -163,7 +163,10 @@ class Trainer(object):
         # a fused flat-arena optimizer; a captured hipGraph step keeps the replicated step (the
         # per-pass optimizer constants live on the host).
         sharded = bool(shard_optimizer) and self.world_size > 1
-        per_bucket = (bool(bucket_optimizer) and not sharded and self.world_size > 1 and not use_hip_graph
+        # (world size 1 on a GPU: the same placement without communication — the slices run on a side
+        # stream under the rest of backward; that form is capturable, the communicating ones are not)
+        per_bucket = (bool(bucket_optimizer) and not sharded
+                      and ((self.world_size > 1 and not use_hip_graph) or (self.world_size == 1 and self.device.type == "cuda"))
                       and hasattr(self.optimizer, "update_range")
                       and getattr(self.optimizer, "arena", None) is getattr(self.model, "param_arena", None)
                       and getattr(self.model, "param_arena", None) is not None)

@@ -199,6 +199,26 @@ def test_linear_fwd_dgrad_wgrad(shape):
     _close(gb, dy[:, :Nout].float().sum(0), 1e-3, 1e-3, "colsum%s" % (shape,))
 
 
+@pytest.mark.parametrize("rows,C,nv", [(4, 4096, 4096), (4, 1024, 1000), (784, 512, 512), (1024, 72, 70),
+                                       (1025, 512, 512), (20000, 64, 64)])
+def test_colsum_single_launch_and_two_pass(rows, C, nv):
+    """rows <= 1024 take the single-launch kernel (small-batch bias gradients), larger ones the
+    two-pass form: both against an fp32 sum, with beta accumulation and a bf16 destination."""
+    k = _k()
+    torch.manual_seed(rows + C)
+    x = _rand(rows, C, scale=0.5)
+    ref = x.float().sum(0)[:nv]
+    tol = 1e-3 * max(1.0, ref.abs().max().item())
+    out = torch.full((nv,), 7.0, device="cuda")
+    k.colsum(x, out, n_valid=nv)
+    _close(out, ref, 1e-3, tol, "colsum(%d,%d)" % (rows, C))
+    k.colsum(x, out, n_valid=nv, beta=1.0)
+    _close(out, 2 * ref, 1e-3, 2 * tol, "colsum beta(%d,%d)" % (rows, C))
+    o16 = torch.zeros(nv, device="cuda", dtype=BF16)
+    k.colsum(x, o16, n_valid=nv)
+    _close(o16, ref, 1e-2, 1e-2 * max(1.0, ref.abs().max().item()), "colsum bf16(%d,%d)" % (rows, C))
+
+
 def test_linear_dropout_statistics_and_determinism():
     k = _k()
     torch.manual_seed(6)
