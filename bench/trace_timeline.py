@@ -1,5 +1,6 @@
-"""Timeline summary of a rocprofv3 --kernel-trace CSV: for the LAST full training step (delimited by
-the fused-SGD kernel), wall time, union of kernel-busy time, time with >= 2 kernels in flight, idle
+"""Timeline summary of a rocprofv3 --kernel-trace CSV: for the LAST full training step (from one
+launch of the first-layer forward kernel to the next: the optimizer runs per bucket on a side stream since
+round 3 and no longer marks the end of a step), wall time, union of kernel-busy time, time with >= 2 kernels in flight, idle
 gaps, busy time per queue, and the largest kernels in start order with their overlap partners.
 usage: trace_timeline.py <dir with *_kernel_trace.csv>"""
 import csv
@@ -14,11 +15,12 @@ ev = []
 for r in rows:
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", r.get("Stream_Id", "?"))))
 ev.sort()
-sgd = [i for i, e in enumerate(ev) if e[2].startswith("sgd_flat_kernel") or "sgd_flat" in e[2]]
-if len(sgd) < 2:
-    sys.exit("need >= 2 optimizer launches in the trace")
-lo, hi = sgd[-2] + 1, sgd[-1] + 1
+first = [i for i, e in enumerate(ev) if "conv1_fprop_kernel" in e[2]]
+if len(first) < 2:
+    sys.exit("need >= 2 steps (conv1_fprop_kernel launches) in the trace")
+lo, hi = first[-2], first[-1]
 step = ev[lo:hi]
+MIN_US = float(os.environ.get("MIN_US", "300"))
 t0, t1 = step[0][0], max(e[1] for e in step)
 print("# one training step from the kernel trace (%d kernels), times in ms" % len(step))
 print("wall %.2f" % ((t1 - t0) / 1e6))
@@ -54,5 +56,5 @@ for g in sorted(gaps, reverse=True)[:8]:
     print("  gap %.3f at +%.2f before %s" % (g[0] / 1e6, g[1] / 1e6, g[2][:60]))
 print("\n| start | dur | queue | kernel |\n|---|---|---|---|")
 for s, e, n, qq in step:
-    if e - s > 300000:
+    if e - s > MIN_US * 1e3:
         print("| %.2f | %.2f | %s | `%s` |" % ((s - t0) / 1e6, (e - s) / 1e6, qq, n[:70]))
