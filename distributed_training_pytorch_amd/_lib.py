@@ -44,6 +44,7 @@ _SIGS = {
     "dtp_avgpool_flatten_bwd": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "dtp_colsum": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "dtp_transpose_bf16": [c_void_p, c_void_p, c_int, c_int, c_long, c_long, c_int, c_long, c_long, c_void_p],
+    "dtp_transpose_multi": [c_void_p, c_int, c_int, c_void_p],
     "dtp_nchw_to_nhwc_bf16": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
                               c_void_p, c_void_p, c_void_p],
     "dtp_conv1_fprop": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,

@@ -138,6 +138,11 @@ class FusedModel(nn.Module):
         side.wait_stream(torch.cuda.current_stream())
         first = True
         with torch.cuda.stream(side):
+            plan = self._derived_transpose_plan(arena)
+            if plan is not None:                      # every plain transpose of the model: ONE launch
+                plan.run()
+                for m, key, out in plan.outputs:
+                    m._set_derived(key, out)
             for m in self.modules():
                 if isinstance(m, FusedLayer):
                     for key, builder in m.derived_builders(needs_input_grad=not first):
@@ -146,6 +151,30 @@ class FusedModel(nn.Module):
             ev = torch.cuda.Event()
             ev.record(side)
         arena.derived_event = ev       # the first backward function that needs a layout waits on it
+
+    def _derived_transpose_plan(self, arena):
+        """Job table over the derived layouts that are plain transposes (``FusedLayer.derived_transposes``),
+        built once per arena: persistent destinations, one ``transpose_multi`` launch per optimizer step."""
+        if os.environ.get("DTP_MULTI_TRANSPOSE", "1") == "0":
+            return None
+        key = (id(arena), arena.flat_lp.data_ptr())
+        cached = self.__dict__.get("_transpose_plan")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        from ..ops import kernels as K
+        jobs, outputs, first = [], [], True
+        for m in self.modules():
+            if isinstance(m, FusedLayer):
+                for k, out, job in m.derived_transposes(needs_input_grad=not first):
+                    jobs.append(job)
+                    outputs.append((m, k, out))
+                first = False if any(True for _ in m.parameters(recurse=False)) else first
+        plan = None
+        if jobs:
+            plan = K.TransposePlan(jobs, arena.device)
+            plan.outputs = outputs
+        self.__dict__["_transpose_plan"] = (key, plan)
+        return plan
 
     def finish_forward(self, y):
         """Optional: join the side stream of ``_prefetch_derived`` at the end of forward (the

@@ -662,6 +662,53 @@ def linear_weight_transpose(w, pad_to=64, out=None):
     return transpose_bf16(w, out, Nout, K, K, ld)
 
 
+def _transpose_job(inp, out, R, Cc, ld_in, ld_out, batch=1, in_bs=0, out_bs=0, in_off=0, out_off=0):
+    """One row of a :class:`TransposePlan` table (the arguments of :func:`transpose_bf16`)."""
+    return [inp.data_ptr() + 2 * in_off, out.data_ptr() + 2 * out_off, ld_in, ld_out, in_bs, out_bs, R, Cc,
+            _cdiv(Cc, 64), _cdiv(R, 64), batch, 0]
+
+
+def conv_weight_to_dgrad_job(w, Cout, Cin, out):
+    """:func:`conv_weight_to_dgrad` as a table row: ``out`` [Cin, 9*Cout] is a persistent buffer."""
+    _need(w, BF16, "w")
+    _need(out, BF16, "out")
+    if w.numel() != Cout * 9 * Cin or out.numel() != Cout * 9 * Cin:
+        raise ValueError("conv_weight_to_dgrad_job: size")
+    return _transpose_job(w, out, Cout, Cin, 9 * Cin, 9 * Cout, batch=9, in_bs=Cin, out_bs=-Cout, out_off=8 * Cout)
+
+
+def linear_weight_transpose_job(w, out):
+    """:func:`linear_weight_transpose` as a table row: ``out`` [K_in, ld >= N_out], padding columns zeroed once."""
+    _need(w, BF16, "w")
+    _need(out, BF16, "out")
+    Nout, Kin = w.shape
+    if out.shape[0] != Kin or out.shape[1] < Nout:
+        raise ValueError("linear_weight_transpose_job: size")
+    return _transpose_job(w, out, Nout, Kin, Kin, out.shape[1])
+
+
+class TransposePlan(object):
+    """Many bf16 transposes as ONE launch (csrc/eltwise.hip ``transpose_multi_kernel``): the job table
+    lives in device memory, sources and destinations are persistent buffers, so the launch has no
+    per-step arguments (hipGraph-friendly) and replaces ~15 launch-sized kernels per optimizer step."""
+
+    def __init__(self, jobs, device):
+        if not jobs:
+            raise ValueError("TransposePlan: no jobs")
+        first = 0
+        rows = []
+        for j in jobs:
+            j = list(j)
+            j[11] = first
+            first += j[8] * j[9] * j[10]
+            rows.append(j)
+        self.n, self.total = len(rows), first
+        self.table = torch.tensor(rows, dtype=torch.int64).reshape(-1).to(device)
+
+    def run(self):
+        check(_lib.hip().dtp_transpose_multi(ptr(self.table), self.n, self.total, stream()), "transpose_multi")
+
+
 def nchw_to_nhwc_bf16(x, c_pad, scale=1.0, mean=None, inv_std=None):
     kinds = {torch.float32: 0, BF16: 1, torch.uint8: 2}
     if x.dtype not in kinds or not x.is_cuda or not x.is_contiguous() or x.dim() != 4:

@@ -33,13 +33,26 @@ OVERLAP_WGRAD = os.environ.get("DTP_OVERLAP_WGRAD", "1") == "1"
 # unmasked linear data gradient without the per-step W^T copy (A/B switch)
 LINEAR_DGRAD_TT = os.environ.get("DTP_LINEAR_DGRAD_TT", "1") == "1"
 FP8_DGRAD = os.environ.get("DTP_FP8_DGRAD", "1") == "1"     # A/B switch: fp8 layers run their data gradient in e5m2 x e4m3
+# Inside a hipGraph capture the weight-gradient kernel of a layer is RECORDED after the layer's data gradient
+# (its dependencies are unchanged: the side stream waited for the fork point before either was queued).  The
+# order of a node's out-edges decides which child the ROCm graph executor keeps on the parent's stream: with
+# the data gradient recorded first the backward chain stays on one hardware queue and the side work hops.
+GRAPH_MAIN_FIRST = os.environ.get("DTP_GRAPH_MAIN_FIRST", "1") == "1"
 _side_streams = {}
+
+
+def _record_late():
+    return GRAPH_MAIN_FIRST and torch.cuda.is_current_stream_capturing()
 # Deferred join (join the side stream only at the end of backward) is OFF by default: it needs
 # record_stream() on every activation the weight-gradient kernels read, which parks those blocks in
 # the caching allocator until the side stream's events retire — with the host running steps ahead
 # the reserved memory grew from 14 GB to 140-235 GB at batch 256 and one run in ~12 hit the limit
 # and ran 5x slower (allocator free/sync storm).  The per-layer join needs no record_stream.
 DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "0") == "1"
+# ... but inside a hipGraph capture it is free: the captured step owns a private memory pool, nothing runs
+# ahead, and the data-gradient chain (the critical path of a launch-bound small-batch step) no longer waits
+# for each layer's weight gradient.  The per-bucket optimizer waits for both streams (parallel/reducer.py).
+GRAPH_DEFER_JOIN = os.environ.get("DTP_GRAPH_DEFER_JOIN", "0") == "1"
 
 
 _pending_join = {}
@@ -53,7 +66,8 @@ def _fork_wgrad(arena, device, *tensors):
     caching allocator with ``record_stream`` so that they are not recycled under it."""
     side = _side_stream(device)
     side.wait_stream(torch.cuda.current_stream())
-    deferred = DEFER_JOIN and (arena.reducer is None or getattr(arena.reducer, "world", 1) == 1)
+    deferred = ((DEFER_JOIN or (GRAPH_DEFER_JOIN and torch.cuda.is_current_stream_capturing()))
+                and (arena.reducer is None or getattr(arena.reducer, "world", 1) == 1))
     if deferred:
         for t in tensors:
             t.record_stream(side)
@@ -118,6 +132,18 @@ class FusedLayer(nn.Module):
         for its backward pass; FusedModel builds them on a side stream during forward."""
         return []
 
+    def derived_transposes(self, needs_input_grad=True):
+        """(key, persistent output tensor, K.TransposePlan row) for the derived layouts that are plain
+        transposes of the bf16 weights: FusedModel runs ALL of a model's in one launch per step."""
+        return []
+
+    def _set_derived(self, key, value):
+        arena = _arena_of(self)
+        if self._derived_epoch != arena.lp_epoch:
+            self._derived = {}
+            self._derived_epoch = arena.lp_epoch
+        self._derived[key] = value
+
     def _cached(self, key, builder):
         arena = _arena_of(self)
         if self._derived_epoch != arena.lp_epoch:
@@ -164,14 +190,17 @@ class _Conv3x3Fn(torch.autograd.Function):
         Co = weight.shape[0]
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
+        late = side is not None and _record_late()
         if side is not None:
             # weight gradient on a second stream, concurrent with the data gradient below: both
             # read dY, neither reads the other's output, and the tail of one kernel's last round of
             # tiles (conv5: 196 tiles on 256 CUs) is filled by the other's workgroups
-            with torch.cuda.stream(side):
-                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-            if K.wgrad_is_persistent(x.shape[3], Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
-                K.stream_delay(K.wgrad_head_start_us)     # the persistent grid must be resident first
+            beta_w = arena.grad_beta(weight)
+            if not late:
+                with torch.cuda.stream(side):
+                    K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
+                if K.wgrad_is_persistent(x.shape[3], Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
+                    K.stream_delay(K.wgrad_head_start_us)     # the persistent grid must be resident first
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         if ctx.has_bias:
@@ -183,6 +212,9 @@ class _Conv3x3Fn(torch.autograd.Function):
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
                                  wd_halves=layer._wd_halves(wd), bn_bwd_src=ctx.bn_src)
+        if late:
+            with torch.cuda.stream(side):
+                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)    # join before the reducer ships the gradient
         if ctx.has_bias:
@@ -215,11 +247,14 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
+        late = side is not None and _record_late()
         if side is not None:
-            with torch.cuda.stream(side):
-                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-            if K.wgrad_is_persistent(Ci, Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
-                K.stream_delay(K.wgrad_head_start_us)
+            beta_w = arena.grad_beta(weight)
+            if not late:
+                with torch.cuda.stream(side):
+                    K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
+                if K.wgrad_is_persistent(Ci, Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
+                    K.stream_delay(K.wgrad_head_start_us)
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
         K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
@@ -229,6 +264,9 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
             dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
                                  wd_halves=layer._wd_halves(wd))
+        if late:
+            with torch.cuda.stream(side):
+                K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
@@ -257,6 +295,14 @@ class _Conv3x3Derived(object):
         if Co == 128 and Ci == 64 and K.two_pass_c128:
             out.append(("wd_halves", lambda: K.split_dgrad_weight(self._cached("wd", out[0][1]), Ci, Co)))
         return out
+
+    def derived_transposes(self, needs_input_grad=True):
+        if not needs_input_grad:
+            return []
+        arena = _arena_of(self)
+        Co, Ci = self.out_channels, self.in_channels
+        out = torch.empty((Ci, 9 * Co), dtype=BF16, device=arena.device)
+        return [("wd", out, K.conv_weight_to_dgrad_job(arena.lp(self.weight), Co, Ci, out))]
 
     def _wd_halves(self, wd):
         """Reduction halves of the dgrad weight for the two-pass 128 -> 64 data gradient (else None)."""
@@ -492,9 +538,12 @@ class _LinearFn(torch.autograd.Function):
             dy = K.relu_mask(dy, y, scale)
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
+        late = side is not None and _record_late()
         if side is not None:
-            with torch.cuda.stream(side):
-                K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
+            beta_w = arena.grad_beta(weight)
+            if not late:
+                with torch.cuda.stream(side):
+                    K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=beta_w)
         else:
             K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=arena.grad_beta(weight))
         K.bias_grad(dy, arena.grad(bias), n_valid=Nout, beta=arena.grad_beta(bias))
@@ -519,6 +568,9 @@ class _LinearFn(torch.autograd.Function):
             arena.wait_derived()
             wt = layer._cached("wt", lambda: K.linear_weight_transpose(arena.lp(weight)))
             dx = K.linear_dgrad(dy, wt, mask_src=x if layer.input_is_relu_out else None, mask_scale=ctx.in_scale)
+        if late:
+            with torch.cuda.stream(side):
+                K.linear_wgrad(dy, x, arena.grad(weight), n_valid=Nout, beta=beta_w)
         if side is not None and not deferred:
             torch.cuda.current_stream().wait_stream(side)
         arena.notify_grad_ready(bias)
@@ -532,6 +584,15 @@ class _LinearDerived(object):
             return []
         arena = _arena_of(self)
         return [("wt", lambda: K.linear_weight_transpose(arena.lp(self.weight)))]
+
+    def derived_transposes(self, needs_input_grad=True):
+        if not self.derived_builders(needs_input_grad):
+            return []
+        arena = _arena_of(self)
+        ld = (self.out_features + 63) // 64 * 64
+        out = (torch.zeros if ld != self.out_features else torch.empty)((self.in_features, ld), dtype=BF16,
+                                                                        device=arena.device)
+        return [("wt", out, K.linear_weight_transpose_job(arena.lp(self.weight), out))]
 
     def _dgrad_without_wt(self, batch):
         """Unmasked data gradients of wide layers (linear1) run on the transposing-read GEMM over

@@ -1196,3 +1196,59 @@ def test_device_augmentation_matches_numpy(shape):
     # other epoch / other seed -> other draws
     p2 = da.draw_params(sel, epoch=4, seed=11, prob=0.7, square=(H == W))
     assert not np.array_equal(da.geom_codes(p), da.geom_codes(p2)) or N < 4
+
+
+def test_transpose_plan_matches_single_transposes():
+    """All derived weight layouts of a model in ONE launch (K.TransposePlan, csrc/eltwise.hip
+    transpose_multi_kernel) == the per-layer conv_weight_to_dgrad / linear_weight_transpose kernels,
+    bit for bit, incl. odd sizes, the rotated-tap negative batch stride and zero padding columns."""
+    k = _k()
+    torch.manual_seed(3)
+    convs = [(64, 3), (128, 64), (512, 256), (72, 40)]          # (Cout, Cin)
+    lins = [(4096, 512), (3, 4096), (100, 72)]                   # (Nout, Kin)
+    jobs, pairs, keep = [], [], []                               # (the plan reads its sources at run())
+    for Co, Ci in convs:
+        w = _rand(Co, 9 * Ci)
+        keep.append(w)
+        out = torch.full((Ci, 9 * Co), 7.0, dtype=BF16, device="cuda")
+        jobs.append(k.conv_weight_to_dgrad_job(w, Co, Ci, out))
+        pairs.append((out, k.conv_weight_to_dgrad(w, Co, Ci)))
+    for No, Ki in lins:
+        w = _rand(No, Ki)
+        keep.append(w)
+        ld = (No + 63) // 64 * 64
+        out = torch.zeros((Ki, ld), dtype=BF16, device="cuda")
+        jobs.append(k.linear_weight_transpose_job(w, out))
+        pairs.append((out, k.linear_weight_transpose(w)))
+    plan = k.TransposePlan(jobs, torch.device("cuda"))
+    plan.run()
+    torch.cuda.synchronize()
+    for i, (got, ref) in enumerate(pairs):
+        assert torch.equal(got, ref), "job %d differs" % i
+
+
+def test_model_derived_layouts_from_one_launch(monkeypatch):
+    """FusedModel builds every conv dgrad filter / classifier W^T with one transpose_multi launch per
+    optimizer step: training is bit-identical to the per-layer launches (DTP_MULTI_TRANSPOSE=0)."""
+    from distributed_training_pytorch_amd.models.vgg16 import VGG16
+    from distributed_training_pytorch_amd.ops.layers import SoftmaxCrossEntropy
+    from distributed_training_pytorch_amd.ops.optim import FusedSGD
+
+    def run(multi):
+        monkeypatch.setenv("DTP_MULTI_TRANSPOSE", "1" if multi else "0")
+        torch.manual_seed(0)
+        model = VGG16(3, 3, True, grad_dtype=BF16).cuda().train()
+        opt = FusedSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        crit = SoftmaxCrossEntropy()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(4, 3, 64, 64, device="cuda", generator=g)
+        y = torch.randint(0, 3, (4,), device="cuda", generator=g)
+        for _ in range(3):
+            opt.zero_grad()
+            crit(model(x), y).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        assert (model.__dict__.get("_transpose_plan") or (None, None))[1] is not None if multi else True
+        return model.param_arena.flat_master.clone()
+    a, b = run(True), run(False)
+    assert torch.equal(a, b)
