@@ -12,6 +12,11 @@ One timed step = zero_grad + ingest (NCHW f32 -> NHWC bf16, or pinned uint8 host
 N > 1) + fused SGD-momentum step on fp32 master weights.  Weak scaling: the per-GPU batch is fixed.
 Rank 0 prints ONE JSON line.
 
+N > 1 on GPUs: before a rank touches its GPU it rehearses the run (3 steps at batch 8, native RCCL transport
+forced) in a throw-away child process on another rendezvous port; if that fails, hangs or crashes on any
+rank, the real run uses the torch.distributed process-group transport and reports it (``preflight``,
+``native_transport_fell_back``).  DTP_PREFLIGHT=0 skips the rehearsal.
+
 Without WORLD_SIZE in the environment and with --gpus N > 1 this script is its own launcher
 (reference run.sh:9-14 starts the ranks with torchrun): the parent process never touches the GPU
 — it does not import torch — and starts N brand-new workers (distributed_training_pytorch_amd/launch.py),
@@ -78,6 +83,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-bucket-optimizer", action="store_true",
                     help="N > 1: run the fused SGD as one pass after the last gradient bucket instead of per "
                          "bucket behind its all-reduce (the default; parallel/reducer.py)")
+    ap.add_argument("--preflight-child", action="store_true",
+                    help="internal: this process is a pre-flight rehearsal of an N > 1 run (see preflight_native)")
     return ap.parse_args(argv)
 
 
@@ -85,6 +92,48 @@ def self_launch(args, argv):
     """Parent side of ``python bench.py --gpus N``: no torch import, no GPU call."""
     from distributed_training_pytorch_amd.launch import spawn_workers
     return spawn_workers(os.path.abspath(__file__), argv, args.gpus)
+
+
+def preflight_native(args, world):
+    """N > 1 on GPUs with the transport left to ``auto``: before this rank touches its GPU, rehearse the
+    run — 3 steps at per-GPU batch 8 with the native RCCL transport FORCED, same model (same gradient
+    buckets), same optimizer placement, bench.py's own cross-rank self-checks — in one throw-away child per
+    rank (launch.preflight).  If the rehearsal fails, hangs or crashes on any rank, the real run takes the
+    torch.distributed process-group transport and says so in its JSON line: a failure that only more than
+    one rank can produce costs a fallback, not the measurement.  (The native path has run on RCCL at world
+    size 1 only from this repository's one-GPU boxes; reference trainer/trainer.py:52 is the DDP it replaces.)
+    DTP_PREFLIGHT=0 skips it, DTP_PREFLIGHT=force runs it for CPU / gloo rehearsals too."""
+    mode = os.environ.get("DTP_PREFLIGHT", "1")
+    if world <= 1 or mode == "0" or args.preflight_child:
+        return None
+    if os.environ.get("DTP_TRANSPORT", "auto").lower() != "auto":
+        return None
+    if mode != "force":
+        if args.device == "cpu" or (args.backend or "nccl") != "nccl" or args.share_device:
+            return None
+        import torch
+        if torch.cuda.device_count() < 1:       # (counting devices does not initialise HIP)
+            return None
+    from distributed_training_pytorch_amd.launch import preflight
+    child = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch-per-gpu", "8", "--preflight-child",
+             "--grad-dtype", args.grad_dtype, "--hip-graph", "off", "--device", args.device]
+    if args.backend:
+        child += ["--backend", args.backend]
+    for flag, on in (("--batch-norm", args.batch_norm), ("--fp8-classifier", args.fp8_classifier),
+                     ("--shard-optimizer", args.shard_optimizer), ("--no-bucket-optimizer", args.no_bucket_optimizer),
+                     ("--share-device", args.share_device)):
+        if on:
+            child.append(flag)
+    if args.image_size != 224:
+        child += ["--image-size", str(args.image_size)]
+    env = {"DTP_NATIVE_INIT_TIMEOUT_S": os.environ.get("DTP_NATIVE_INIT_TIMEOUT_S", "60"),
+           "DTP_PG_TIMEOUT_S": os.environ.get("DTP_PG_TIMEOUT_S", "180")}
+    if mode != "force":
+        env["DTP_TRANSPORT"] = "native"
+    t0 = time.perf_counter()
+    ok, reason = preflight(os.path.abspath(__file__), child,
+                           timeout_s=float(os.environ.get("DTP_PREFLIGHT_TIMEOUT_S", "270")), extra_env=env)
+    return dict(ok=bool(ok), reason=reason, seconds=round(time.perf_counter() - t0, 1))
 
 
 def main(argv=None):
@@ -98,6 +147,11 @@ def main(argv=None):
         sys.exit(self_launch(args, argv))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it here
+    if args.preflight_child and os.environ.get("DTP_PREFLIGHT_INJECT"):      # tests: a rehearsal that fails / hangs
+        if os.environ["DTP_PREFLIGHT_INJECT"] == "hang":
+            time.sleep(3600)
+        sys.exit(3)
+    pre = preflight_native(args, int(os.environ.get("WORLD_SIZE", "1")))
     # stdout carries ONE line, the JSON result of rank 0.  Libraries below us write there too (RCCL's
     # version banner and WARN lines, gloo's "Rank 0 is connected to ..." notices), so file descriptor 1
     # points at stderr for the duration of the run and is restored for the result line.
@@ -138,6 +192,19 @@ def main(argv=None):
         if backend == "nccl":
             kw["device_id"] = dev
         dist.init_process_group(backend, **kw)
+    if pre is not None and world > 1:
+        # every rank takes the same transport: the rehearsal counts only if it passed everywhere
+        from distributed_training_pytorch_amd.parallel import comm
+        all_ok = comm.all_reduce_scalars([1.0 if pre["ok"] else 0.0], op="min")[0] >= 1.0
+        if not all_ok:
+            os.environ["DTP_TRANSPORT"] = "torch"
+            os.environ["DTP_NATIVE_FELL_BACK"] = "1"
+            os.environ["DTP_NATIVE_FALLBACK_REASON"] = "pre-flight rehearsal of the native transport failed: %s" % (
+                pre["reason"] or "on another rank")
+            if rank == 0:
+                print("[bench] %s; this run uses the torch.distributed process-group transport"
+                      % os.environ["DTP_NATIVE_FALLBACK_REASON"], file=sys.stderr, flush=True)
+        pre["all_ranks_ok"] = bool(all_ok)
 
     from distributed_training_pytorch_amd.data.synthetic import DeviceBatchSource
     from distributed_training_pytorch_amd.models.vgg16 import VGG16
@@ -307,6 +374,7 @@ def main(argv=None):
             "native_transport_fallback_reason": info.get("reason"),
             "bucket_mbytes": [round(b["mbytes"], 3) for b in dp.reducer.bucket_summary()],
             "rccl_env_applied_by_bench": applied_env,
+            "preflight": pre,       # N > 1: rehearsal of the native transport in throw-away children (None: not run)
             "config": {"model": "VGG16 (%s, %d classes, %dM params)" % (
                            "BN" if args.batch_norm else "no BN", args.classes,
                            round(sum(p.numel() for p in model.parameters()) / 1e6)),

@@ -152,3 +152,57 @@ def spawn_workers(script, argv, nproc, nnodes=1, node_rank=0, master_addr="127.0
             log("job failed with %d: restart %d of %d" % (rc, restarts, max_restarts))
             continue
         return rc
+
+
+def preflight_port(master_port):
+    """Rendezvous port of the pre-flight children: a fixed function of the job's port, so that every
+    rank derives the same one without talking to the others."""
+    p = int(master_port)
+    return 20000 + (p * 7 + 4099) % 20000
+
+
+def preflight(script, argv, timeout_s=240.0, extra_env=None, python=None):
+    """Rehearse a multi-rank job in ONE throw-away child process per rank before the real run.
+
+    Called by every rank of a job (``RANK`` / ``WORLD_SIZE`` / ``MASTER_ADDR`` / ``MASTER_PORT`` in the
+    environment) BEFORE it touches the GPU: starts ``python script *argv`` with the same rank
+    variables on another rendezvous port and waits for it.  The children form a job of their own, so a
+    code path that cannot be exercised on this rank's own resources alone (a second RCCL communicator
+    between exactly these GPUs, the C++ bucket scheduler on it) either works end to end there, or
+    fails / hangs THERE — in processes that are killed (exact PIDs) without harming the caller, which
+    then picks the conservative path.  A foreign launcher (torchrun) restarts nothing, so this is the
+    only place where such a failure can still cost a fallback instead of the job.
+
+    Returns ``(ok, reason)``; never raises for a failing child."""
+    import tempfile
+    env = dict(os.environ)
+    for k, v in rccl_env_defaults().items():
+        env.setdefault(k, v)
+    env.update(extra_env or {})
+    env["MASTER_PORT"] = str(preflight_port(os.environ.get("MASTER_PORT", "29500")))
+    # the children rendezvous among themselves: rank 0's child hosts the store, not the elastic agent
+    for k in ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"):
+        env.pop(k, None)
+    env["DTP_PREFLIGHT"] = "0"
+    cmd = [python or sys.executable, "-u", script] + list(argv)
+    t0 = time.time()
+    with tempfile.TemporaryFile(mode="w+b") as err:
+        try:
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=err, start_new_session=True)
+        except OSError as e:
+            return False, "pre-flight child could not be started: %s" % e
+        try:
+            rc = proc.wait(timeout=timeout_s)
+            reason = None if rc == 0 else "pre-flight child exited with %d after %.0f s" % (rc, time.time() - t0)
+        except subprocess.TimeoutExpired:
+            _terminate([proc], grace_s=3.0)
+            rc, reason = -1, "pre-flight child still running after %.0f s: killed" % timeout_s
+        if rc != 0:
+            try:
+                err.seek(0)
+                tail = err.read()[-1500:].decode("utf-8", "replace").strip().splitlines()
+                if tail:
+                    reason += " (%s)" % " | ".join(tail[-3:])
+            except Exception:
+                pass
+    return rc == 0, reason

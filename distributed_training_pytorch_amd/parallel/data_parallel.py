@@ -58,7 +58,8 @@ class DataParallel(nn.Module):
         import os
         want = os.environ.get("DTP_TRANSPORT", "auto").lower()
         info = dict(requested=want, kind="torch", fell_back=os.environ.get("DTP_NATIVE_FELL_BACK") == "1",
-                    reason="relaunched by the self-launcher after a native bring-up timeout"
+                    reason=os.environ.get("DTP_NATIVE_FALLBACK_REASON",
+                                          "relaunched by the self-launcher after a native bring-up timeout")
                     if os.environ.get("DTP_NATIVE_FELL_BACK") == "1" else None)
         if device.type != "cuda" or not comm.is_dist() or comm.world_size() == 1 or want == "torch":
             t = TorchPGTransport()

@@ -810,6 +810,32 @@ def test_two_ranks_sharing_the_gpu_over_gloo(tmp_path, transport, world):
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % i for i in range(world)]
 
 
+def test_bench_preflight_rehearsal_on_a_shared_gpu_over_gloo():
+    """bench.py under torch.distributed.run with two ranks on cuda:0 (gloo) and the pre-flight rehearsal
+    forced: each rank first runs a throw-away child (3 steps at batch 8 on the HIP kernels, its own
+    rendezvous port, the native bring-up failing over to the process group on the duplicated GPU), then
+    the real run; ONE JSON line, both ranks seen, parameters agree, rehearsal recorded as passed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DTP_PREFLIGHT="force", DTP_NATIVE_INIT_TIMEOUT_S="15", OMP_NUM_THREADS="2",
+               DTP_PG_TIMEOUT_S="60")
+    env.pop("DTP_TRANSPORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29650 + os.getpid() % 100),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--batch-per-gpu", "4",
+           "--image-size", "64", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["preflight"]["ok"] is True and j["preflight"]["all_ranks_ok"] is True
+    assert j["ranks_seen"] == 2 and j["params_agree_across_ranks"] is True and j["dtype"] == "bf16"
+
+
 def test_every_sync_mode_on_a_shared_gpu_over_gloo(tmp_path):
     """tests/dist_worker.py::scenario_gpu_modes with two ranks sharing cuda:0 over gloo: VGG16-BN with
     dropout through all-reduce, the per-bucket optimizer (default) and the sharded optimizer on the GPU

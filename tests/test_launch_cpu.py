@@ -68,6 +68,45 @@ def test_bench_under_torch_distributed_run_cpu():
     assert j["grad_transport_selfcheck_ok"] is True
 
 
+def _torchrun_bench(extra_env, port=None):
+    from distributed_training_pytorch_amd.launch import free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port or free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--device", "cpu", "--batch-per-gpu", "4", "--image-size", "32", "--steps", "2", "--warmup", "1"]
+    return subprocess.run(cmd, cwd=ROOT, env=dict(ENV, **extra_env), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, timeout=900)
+
+
+def test_bench_preflight_rehearsal_under_torchrun_cpu():
+    """N > 1 under a foreign launcher: every rank rehearses the run in a throw-away child on another
+    rendezvous port (bench.preflight_native / launch.preflight) before the real one.  (a) the rehearsal
+    passes: the run proceeds as it would have, still ONE line on stdout; (b) it fails on every rank, (c) it
+    hangs on every rank and is killed at its deadline: the real run still happens, on the process-group
+    transport, and its JSON says why.  CPU / gloo stands in for the GPUs (DTP_PREFLIGHT=force)."""
+    r = _torchrun_bench(dict(DTP_PREFLIGHT="force"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-3000:]
+    j = json.loads(lines[0])
+    assert j["preflight"]["ok"] is True and j["preflight"]["all_ranks_ok"] is True
+    assert j["native_transport_fell_back"] is False and j["ranks_seen"] == 2
+    for inject, timeout_s, word in (("fail", "120", "exited with 3"), ("hang", "4", "killed")):
+        r = _torchrun_bench(dict(DTP_PREFLIGHT="force", DTP_PREFLIGHT_INJECT=inject, DTP_PREFLIGHT_TIMEOUT_S=timeout_s))
+        assert r.returncode == 0, r.stderr[-3000:]
+        j = _json_line(r.stdout)
+        assert j["preflight"]["ok"] is False and j["preflight"]["all_ranks_ok"] is False
+        assert j["native_transport_fell_back"] is True and word in j["native_transport_fallback_reason"]
+        assert j["grad_transport"] == "TorchPGTransport" and j["ranks_seen"] == 2 and j["grad_transport_selfcheck_ok"]
+        assert "pre-flight rehearsal" in r.stderr
+
+
+def test_preflight_port_is_a_pure_function_of_the_job_port():
+    from distributed_training_pytorch_amd.launch import preflight_port
+    for p in (29500, 12345, 65535, 1024):
+        q = preflight_port(p)
+        assert q == preflight_port(str(p)) and 20000 <= q < 40000 and q != p
+
+
 def test_bench_single_process_path_is_unchanged_cpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--batch-per-gpu", "2",
                         "--image-size", "32", "--steps", "1", "--warmup", "1"], cwd=ROOT, env=ENV,
