@@ -1,5 +1,5 @@
-"""Fused flat SGD alone on the GPU over a VGG16-sized arena (134 M parameters, bf16 gradients) and, second,
-next to a stream of small kernels on another stream: how long does a 10 us kernel take while the update runs?
+"""Fused flat SGD alone on the GPU over a VGG16-sized arena (134 M parameters, bf16 gradients).
+(What a full-chip optimizer grid does to a kernel launched next to it is in profiles/76_*: a replay timeline.)
 DTP_OPT_GRID_CAP selects the optimizer grid (512 = 2 workgroups per CU, the default; 4096 = the old grid)."""
 import json
 import os
@@ -38,24 +38,8 @@ def main():
     torch.cuda.synchronize()
     alone = e0.elapsed_time(e1) / 20
     gb = n * (4 + 2 + 4 + 4 + 4 + 2) / 1e9
-    # small kernels next to it
-    side = torch.cuda.Stream()
-    a = torch.randn(256, 1024, device=dev)
-    small = []
-    for _ in range(5):
-        side.wait_stream(s0)
-        sgd(s0)
-        with torch.cuda.stream(side):
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-            evs[0].record()
-            for k in range(20):
-                a.mul_(1.0001)
-                evs[k + 1].record()
-        torch.cuda.synchronize()
-        small.append(max(evs[k].elapsed_time(evs[k + 1]) for k in range(20)))
     print(json.dumps({"grid_cap": os.environ.get("DTP_OPT_GRID_CAP", "512 (default)"), "sgd_ms": round(alone, 4),
-                      "TB_per_s": round(gb / alone, 3),
-                      "worst_small_kernel_ms_next_to_sgd": round(max(small), 4)}))
+                      "TB_per_s": round(gb / alone, 3)}))
 
 
 if __name__ == "__main__":

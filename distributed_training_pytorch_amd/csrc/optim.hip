@@ -29,7 +29,7 @@ DTP_DEVINL f32x4_t load_grad4(const void* g, size_t i4) {
 #define OPT_UNROLL 4
 
 template <bool GRAD_BF16>
-__global__ void sgd_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ mom,
+__global__ __launch_bounds__(256) void sgd_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ mom,
                                 bf16_t* __restrict__ lp, size_t n4, float lr, float momentum, float dampening,
                                 float wd, float grad_scale, int nesterov, int first_step) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -73,7 +73,7 @@ __global__ void sgd_flat_kernel(float* __restrict__ p, const void* __restrict__ 
 
 // AdamW (decoupled weight decay): p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 template <bool GRAD_BF16>
-__global__ void adamw_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const void* __restrict__ g, float* __restrict__ m,
                                   float* __restrict__ v, bf16_t* __restrict__ lp, size_t n4, float lr, float beta1,
                                   float beta2, float eps, float wd, float grad_scale, float bc1, float bc2_sqrt) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
