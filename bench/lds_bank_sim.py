@@ -4,8 +4,11 @@ of a 64-byte-row image ([rows][32 bf16], four 16-byte chunks) is conflict-free f
   (i)   ds_read_b128 fragment reads  (lane -> row lane & 15, logical chunk lane >> 4),
   (ii)  ds_write_b128 of the rows    (lane -> row, one logical chunk per instruction),
   (iii) ds_read_b64_tr_b16 reads     (lane (g4, q, pp) -> row 8*g4 + q (+4), chunk 2j + (pp >> 1), half pp & 1).
-  python bench/lds_bank_sim.py"""
+  python bench/lds_bank_sim.py
+  python bench/lds_bank_sim.py --shifted     # round 3: swizzle of the shared activation image (igemm.hip PIPE 3):
+                                             # 128-byte rows read at row shifts {0, 1, 2} and {0, 2, 4}"""
 import itertools
+import sys
 
 G128 = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
         list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
@@ -45,7 +48,49 @@ def score(M):
     return r, w, t
 
 
+def shifted_conflicts(s, shifts, bases=(0, 16, 32, 48)):
+    """Worst / mean ways of the ds_read_b128 fragment reads (lane -> row base + (lane & 15) + shift, chunk
+    (lane >> 4) ^ s(row)) of a 128-byte-row image, over the four lane groups."""
+    worst, total, n = 1, 0, 0
+    for d in shifts:
+        for base in bases:
+            for g in G128:
+                acc = []
+                for l in g:
+                    row = base + (l & 15) + d
+                    acc.append((row * 128 + ((((l >> 4) ^ s(row)) & 7) << 4), 16))
+                w = ways(acc, 64)
+                worst, total, n = max(worst, w), total + w, n + 1
+    return worst, total / n
+
+
+def search_shifted():
+    cur = lambda row: (row >> 1) & 7
+    print("PIPE 2's (row >> 1) & 7: aligned", shifted_conflicts(cur, (0,)), " shifts 0,1,2", shifted_conflicts(cur, (0, 1, 2)),
+          " shifts 0,2,4", shifted_conflicts(cur, (0, 2, 4)))
+    good = []
+    for bits in itertools.product([0, 1], repeat=15):
+        M = [bits[0:5], bits[5:10], bits[10:15]]
+
+        def s(row, M=M):
+            b = [(row >> i) & 1 for i in range(5)]
+            return sum(((sum(M[k][i] & b[i] for i in range(5)) & 1) << k) for k in range(3))
+        if shifted_conflicts(s, (0, 1, 2))[0] == 1:
+            good.append((shifted_conflicts(s, (0, 2, 4)), M))
+    good.sort()
+    print("%d of 32768 GF(2)-linear maps of row bits 0..4 are conflict-free for shifts {0, 1, 2};" % len(good),
+          "%d of them also for {0, 2, 4}.  First ones (rows of the map = chunk bits 0, 1, 2):" % sum(1 for g in good if g[0][0] == 1))
+    for sc, M in good[:6]:
+        print(sc, M)
+    chosen = lambda row: (((row >> 2) & 1) << 1) | (((row >> 1) & 1) << 2)
+    print("igemm.hip swz_img = bit2 -> chunk bit 1, bit1 -> chunk bit 2:", shifted_conflicts(chosen, (0, 1, 2)),
+          shifted_conflicts(chosen, (0, 2, 4)))
+
+
 if __name__ == "__main__":
+    if "--shifted" in sys.argv:
+        search_shifted()
+        sys.exit(0)
     res = sorted((score((b[:4], b[4:])), (b[:4], b[4:])) for b in itertools.product([0, 1], repeat=8))
     print("(fragment reads, row writes, transposed reads) worst-case ways, then the map (chunk bit 0 row, chunk bit 1 row):")
     for sc, M in res[:6]:

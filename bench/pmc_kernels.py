@@ -12,6 +12,7 @@ from distributed_training_pytorch_amd.ops import kernels as k  # noqa: E402
 
 BF16 = torch.bfloat16
 N = int(os.environ.get("PMC_BATCH", "64"))
+POOL = os.environ.get("PMC_POOL", "1") == "1"
 torch.manual_seed(0)
 
 
@@ -26,6 +27,8 @@ def conv_set(C, Co, HW):
         k.conv3x3_fprop(x, w, b, True)
         k.conv3x3_dgrad(dy, wd, mask_src=x)
         k.conv3x3_wgrad(dy, x, gw)
+        if POOL and k.conv_pool_fusable(C, Co, HW, HW, N=N):     # round 3: conv + ReLU + max-pool in one kernel
+            k.conv3x3_relu_pool_fprop(x, w, b)
     torch.cuda.synchronize()
 
 
