@@ -54,6 +54,14 @@ def pick_igemm(M, N, ksteps):
     # are LDS-fill bound and prefer the plain 256x64 loop (cfg 2).
     if N > 128:
         order = [16, 3]     # 8-phase counted-vmcnt schedule: +10-18 % over the 2-stage loops
+        # long reductions over few output tiles (linear1 at batch 1024: 4 x 16 tiles of 256x256, 392 K-steps):
+        # split K so that the 8-phase tiles fill the chip once — 0.344 ms (128x128 tiles, 612 TF/s) -> 0.205 ms
+        # (1,027 TF/s), bench/bench_fc.py; linear2 (64 K-steps) stays on the 128x128 tiles (measured faster)
+        t256 = _cdiv(M, 256) * _cdiv(N, 256)
+        if N_CU // 8 <= t256 < N_CU // 2 and ksteps >= 128:
+            ns = max(1, N_CU // t256)
+            if ksteps // ns >= 32:
+                return 16, ns
     elif N > 64:
         order = [3]         # re-swept after the chunk-major K order: 128x128 beats the pipelined 256x128
         # 512x128 8-phase tile (one workgroup per CU): +11 % on conv2_2 forward, +3 % on its data
