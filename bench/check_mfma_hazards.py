@@ -124,11 +124,17 @@ def main():
     files = sys.argv[1:] or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     bad = 0
     with tempfile.TemporaryDirectory() as td:
-        for f in files:
+        defs = os.environ.get("DTP_BUILD_DEFS", "").split()
+
+        def to_asm(f):
             out = os.path.join(td, os.path.basename(f) + ".s")
-            defs = os.environ.get("DTP_BUILD_DEFS", "").split()
-            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", *defs, "-I", CSRC,
-                                "-S", "--cuda-device-only", "-o", out, f], capture_output=True, text=True)
+            return out, subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", *defs,
+                                        "-I", CSRC, "-S", "--cuda-device-only", "-o", out, f], capture_output=True, text=True)
+        # the compilations are independent: run them side by side (igemm.hip alone takes a minute)
+        import concurrent.futures
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(files), os.cpu_count() or 1)) as ex:
+            compiled = list(ex.map(to_asm, files))
+        for f, (out, r) in zip(files, compiled):
             if r.returncode != 0:
                 print("%s: does not compile to assembly\n%s" % (f, r.stderr[-2000:]))
                 return 2

@@ -57,12 +57,17 @@ def test_bench_under_torch_distributed_run_cpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu",
            "--batch-per-gpu", "4", "--image-size", "32", "--steps", "2", "--warmup", "1"]
-    r = subprocess.run(cmd, cwd=ROOT, env=ENV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    # (DTP_PREFLIGHT=force: the pre-flight rehearsal that GPU runs do at N > 1 runs here too — a throw-away
+    # child per rank on another rendezvous port before the real run — and must leave stdout untouched)
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(ENV, DTP_PREFLIGHT="force"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-3000:]                    # ONE line on stdout, the JSON
     j = json.loads(lines[0])
     assert all(k in j for k in DRIVER_KEYS), sorted(j)
+    assert j["preflight"]["ok"] is True and j["preflight"]["all_ranks_ok"] is True
+    assert j["native_transport_fell_back"] is False
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 2 and j["warmup"] == 1
     assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["config"]["global_batch"] == 8
     assert j["grad_transport_selfcheck_ok"] is True
@@ -79,17 +84,10 @@ def _torchrun_bench(extra_env, port=None):
 
 def test_bench_preflight_rehearsal_under_torchrun_cpu():
     """N > 1 under a foreign launcher: every rank rehearses the run in a throw-away child on another
-    rendezvous port (bench.preflight_native / launch.preflight) before the real one.  (a) the rehearsal
-    passes: the run proceeds as it would have, still ONE line on stdout; (b) it fails on every rank, (c) it
-    hangs on every rank and is killed at its deadline: the real run still happens, on the process-group
-    transport, and its JSON says why.  CPU / gloo stands in for the GPUs (DTP_PREFLIGHT=force)."""
-    r = _torchrun_bench(dict(DTP_PREFLIGHT="force"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout[-3000:]
-    j = json.loads(lines[0])
-    assert j["preflight"]["ok"] is True and j["preflight"]["all_ranks_ok"] is True
-    assert j["native_transport_fell_back"] is False and j["ranks_seen"] == 2
+    rendezvous port (bench.preflight_native / launch.preflight) before the real one.  (The passing rehearsal is
+    part of test_bench_under_torch_distributed_run_cpu.)  Here it (a) fails on every rank, (b) hangs on every
+    rank and is killed at its deadline: the real run still happens, on the process-group transport, and its
+    JSON says why.  CPU / gloo stands in for the GPUs (DTP_PREFLIGHT=force)."""
     for inject, timeout_s, word in (("fail", "120", "exited with 3"), ("hang", "4", "killed")):
         r = _torchrun_bench(dict(DTP_PREFLIGHT="force", DTP_PREFLIGHT_INJECT=inject, DTP_PREFLIGHT_TIMEOUT_S=timeout_s))
         assert r.returncode == 0, r.stderr[-3000:]
