@@ -300,7 +300,7 @@ static int launch_wg(const WgradParams& p0, int nsplit, hipStream_t stream) {
   return DTP_CHECK_LAUNCH();
 }
 
-// second-generation kernels (csrc/wgrad2.hip): cfg 8 = 256x256 tile, cfg 9 = 128x128 tile
+// second-generation kernels (csrc/wgrad2.hip): cfg 8 = 256x256 tile, cfg 9 = 128x128 tile, cfg 10 = 256x256 8-phase
 extern "C" int dtp_wgrad_tt2_launch(const void* dY, const void* X, void* out, float* partial, int K, int M, int Ntot,
                                     int C, int taps, int H, int W, int lda, int ldb, int out_fp32, float beta,
                                     int nsplit, int ksteps_total, int ksteps_per_split, int cfg, hipStream_t stream);
@@ -334,8 +334,8 @@ extern "C" int dtp_wgrad_tt(const void* dY, const void* X, void* out, float* par
     case 2: rc = DTP_WG(128, 64, 2, 2); break;
     case 3: rc = DTP_WG(64, 128, 2, 2); break;
     case 4: rc = DTP_WG(64, 64, 2, 2); break;
-    case 8: case 9:
-      if (t9 && (C % (cfg == 8 ? 256 : 128))) return -20;
+    case 8: case 9: case 10:      // 10 = the 256x256 tile on the 8-phase schedule (wgrad_tt8_kernel)
+      if (t9 && (C % (cfg == 9 ? 128 : 256))) return -20;
       rc = dtp_wgrad_tt2_launch(dY, X, out, partial, K, M, Ntot, C, taps, H, W, lda, ldb, out_fp32, beta, nsplit,
                                 p.ksteps_total, p.ksteps_per_split, cfg - 8, stream);
       break;

@@ -16,6 +16,7 @@ from .._lib import ptr, stream, check, workspace
 
 BF16 = torch.bfloat16
 N_CU = 256
+wgrad_8phase = _os.environ.get("DTP_WGRAD_8PHASE", "1") == "1"     # 256x256 weight-gradient tile on the 8-phase schedule
 
 # (BM, BN) per igemm cfg id / per wgrad cfg id — must match csrc/igemm.hip, csrc/wgrad.hip
 IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (128, 64), 16: (256, 256), 17: (512, 128),
@@ -24,7 +25,8 @@ IGEMM_TILES = {0: (256, 256), 1: (256, 128), 2: (256, 64), 3: (128, 128), 4: (12
                20: (256, 256), 21: (384, 128),   # cfg 18 / 19 + ReLU + 2x2 max-pool in the epilogue (pooled output)
                8: (256, 256), 9: (256, 128), 10: (256, 64), 11: (128, 128), 12: (128, 64)}
 WGRAD_TILES = {2: (128, 64), 3: (64, 128), 4: (64, 64),    # wgrad.hip: small-tile fallbacks (narrow outputs)
-               8: (256, 256), 9: (128, 128)}   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
+               8: (256, 256), 9: (128, 128),   # wgrad2.hip: asm transposed reads (DMA stays in flight), SRD staging
+               10: (256, 256)}                 # wgrad2.hip: the 256x256 tile on the 8-phase schedule
 
 _overrides = {}   # tuning hooks: {"igemm": fn(M, N, K, taps) -> (cfg, nsplit), "wgrad": ...}
 
@@ -130,7 +132,13 @@ def pick_wgrad(M, C, taps, ksteps):
             nsplit = min(n, max_split)
             if n <= max_split and tiles * n >= 0.85 * slots * rounds:
                 break
-    return cfg, max(1, nsplit)
+    nsplit = max(1, nsplit)
+    if cfg == 8 and wgrad_8phase and ksteps // nsplit >= 160:
+        # the same tile on the 8-phase schedule (wgrad_tt8_kernel): same sums, bit for bit; +1-4 % isolated on
+        # long reductions (its longer prologue loses on short ones: 112 K-tiles per split -2.5 %), +1.15 % on
+        # the full step where it shares the chip with the data gradient (bench/r3_wg8.sh)
+        cfg = 10
+    return cfg, nsplit
 
 
 class _ColsumSlot(object):

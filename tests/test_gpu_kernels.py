@@ -1252,3 +1252,54 @@ def test_model_derived_layouts_from_one_launch(monkeypatch):
         return model.param_arena.flat_master.clone()
     a, b = run(True), run(False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [(2, 28, 28, 256, 256, 1), (3, 14, 14, 256, 512, 1), (5, 14, 14, 512, 256, 3),
+                                  (1, 8, 8, 256, 256, 1), (2, 10, 6, 256, 304, 2)])
+def test_wgrad_8phase_is_bit_identical_to_the_two_stage_kernel(case):
+    """wgrad2.hip cfg 10 (256x256 tile on the 8-phase schedule: half-tile slots, counted vmcnt, wave rows staggered
+    by one barrier) sums the same products in the same order as cfg 8: bit-identical weight gradients, incl.
+    K tails, odd K-tile counts (the all-zero padding tile), M tails and split-K; and both match the f32 reference."""
+    k = _k()
+    N, H, W, C, Co, ns = case
+    torch.manual_seed(5)
+    x, dy = _rand(N, H, W, C), _rand(N, H, W, Co, scale=0.1)
+    outs = []
+    try:
+        for cfg in (8, 10):
+            k._overrides["wgrad"] = lambda M, C_, taps, ks, cfg=cfg: (cfg, ns)
+            gw = torch.full((Co, 9 * C), 3.0, device="cuda")
+            k.conv3x3_wgrad(dy, x, gw)
+            torch.cuda.synchronize()
+            outs.append(gw)
+    finally:
+        k._overrides.pop("wgrad", None)
+    assert torch.equal(outs[0], outs[1])
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    w = torch.zeros(Co, C, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(xr, w, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9 * C)
+    _close(outs[1], ref, 2e-2, 2e-2 * ref.abs().max().item(), "wgrad 8-phase vs f32 reference")
+
+
+def test_wgrad_8phase_linear_form_is_bit_identical():
+    k = _k()
+    torch.manual_seed(6)
+    for B, Nout, Kin, ns in ((512, 4096, 1024, 1), (200, 300, 1000, 1), (64, 256, 6272, 2)):
+        x = _rand(B, Kin)
+        ld = (Nout + 63) // 64 * 64
+        dy = torch.zeros(B, ld, device="cuda", dtype=BF16)
+        dy[:, :Nout] = _rand(B, Nout, scale=0.1)
+        outs = []
+        try:
+            for cfg in (8, 10):
+                k._overrides["wgrad"] = lambda M, C_, taps, ks, cfg=cfg, ns=ns: (cfg, ns)
+                gw = torch.full((Nout, Kin), 3.0, device="cuda")
+                k.linear_wgrad(dy, x, gw, n_valid=Nout)
+                torch.cuda.synchronize()
+                outs.append(gw)
+        finally:
+            k._overrides.pop("wgrad", None)
+        assert torch.equal(outs[0], outs[1]), (B, Nout, Kin, ns)
+        ref = dy[:, :Nout].float().t() @ x.float()
+        _close(outs[1], ref, 2e-2, 2e-2 * ref.abs().max().item(), "linear wgrad 8-phase")
