@@ -323,7 +323,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void wgrad_tt2_kernel(const Wgrad2P
 // A0B0 -> A0B1 -> A1B1 -> A1B0 so one operand half stays in registers, every phase = issue ONE half-tile of
 // LDS-DMA, counted `s_waitcnt vmcnt(8)` (four half-tiles stay in flight), raw s_barrier, 16 MFMAs, s_barrier;
 // the two wave rows (= the two waves of every SIMD) are staggered by one barrier, so one's transposed reads
-// and their LDS latency run under the other's MFMAs.  Why now: in-kernel stamps of the 2-stage loop above
+// and their LDS latency run under the other's MFMAs.  The last two quadrants (A1B1, A1B0) are ONE phase here:
+// A1B0 reads nothing new, so its MFMAs join A1B1's behind the same barrier (both half-tile issues of the pair
+// go out in front of it; the counted waits are unchanged because the issue ORDER is): 6 barriers-pairs per
+// two K-tiles instead of 8 and a 32-MFMA block that covers the other group's 24-read phase: +2-4 % isolated.  Why now: in-kernel stamps of the 2-stage loop above
 // (profiles/86_*) show a wave needing ~2,490 cycles for the 1,024 cycles of MFMAs of its K-step — 48
 // transposed 8-byte reads with at most 16 in flight are three LDS round trips nothing of its own covers —
 // and waiting another ~1,160 cycles in the K-step's barrier for its SIMD-mate to do the same.  Round 1's
@@ -509,11 +512,10 @@ __global__ __launch_bounds__(512) void wgrad_tt8_kernel(const Wgrad2Params p) {
     W8_READ_B(1, b1l, b1h)                                                     // P2
     issue_A(I1{}, I1{}, t + 1);
     W8_SYNC_IN() W8_WAIT_B(b1l, b1h) W8_GO() W8_MMA(0, 1, b1l, b1h) W8_SYNC_OUT()
-    W8_READ_A(1)                                                               // P3
+    W8_READ_A(1)                                                               // P3 + P4: nothing new to read for A1B0
     issue_B(I0{}, I0{}, t + 2);
-    W8_SYNC_IN() W8_WAIT_A() W8_GO() W8_MMA(1, 1, b1l, b1h) W8_SYNC_OUT()
-    issue_A(I0{}, I0{}, t + 2);                                                // P4
-    W8_SYNC_IN() W8_GO() W8_MMA(1, 0, b0l, b0h) W8_SYNC_OUT()
+    issue_A(I0{}, I0{}, t + 2);
+    W8_SYNC_IN() W8_WAIT_A() W8_GO() W8_MMA(1, 1, b1l, b1h) W8_MMA(1, 0, b0l, b0h) W8_SYNC_OUT()
     W8_FLIP(DB)
     // ---- K-tile t+1 (dbuf 1); with an odd tile count an all-zero tile (loads past kend return zeros)
     W8_READ_A(0) W8_READ_B(0, b0l, b0h)                                        // P5
@@ -522,11 +524,10 @@ __global__ __launch_bounds__(512) void wgrad_tt8_kernel(const Wgrad2Params p) {
     W8_READ_B(1, b1l, b1h)                                                     // P6
     issue_A(I1{}, I0{}, t + 2);
     W8_SYNC_IN() W8_WAIT_B(b1l, b1h) W8_GO() W8_MMA(0, 1, b1l, b1h) W8_SYNC_OUT()
-    W8_READ_A(1)                                                               // P7
+    W8_READ_A(1)                                                               // P7 + P8
     issue_B(I0{}, I1{}, t + 3);
-    W8_SYNC_IN() W8_WAIT_A() W8_GO() W8_MMA(1, 1, b1l, b1h) W8_SYNC_OUT()
-    issue_A(I0{}, I1{}, t + 3);                                                // P8
-    W8_SYNC_IN() W8_GO() W8_MMA(1, 0, b0l, b0h) W8_SYNC_OUT()
+    issue_A(I0{}, I1{}, t + 3);
+    W8_SYNC_IN() W8_WAIT_A() W8_GO() W8_MMA(1, 1, b1l, b1h) W8_MMA(1, 0, b0l, b0h) W8_SYNC_OUT()
     W8_FLIP(-DB)
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();    // pair the stagger barrier of the other group
