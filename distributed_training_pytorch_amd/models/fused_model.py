@@ -119,6 +119,7 @@ class FusedModel(nn.Module):
             self.param_arena.refresh_lp()
             from ..ops import layers as L
             L._pending_join.clear()          # a backward pass that raised must not block future joins
+            del L._keepalive[:]
             if self.training and torch.is_grad_enabled():
                 self._prefetch_derived(x.device)
         return x

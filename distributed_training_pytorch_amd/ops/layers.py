@@ -48,7 +48,12 @@ def _record_late():
 # the caching allocator until the side stream's events retire — with the host running steps ahead
 # the reserved memory grew from 14 GB to 140-235 GB at batch 256 and one run in ~12 hit the limit
 # and ran 5x slower (allocator free/sync storm).  The per-layer join needs no record_stream.
-DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "0") == "1"
+DEFER_JOIN = os.environ.get("DTP_DEFER_JOIN", "0") in ("1", "2")
+# "2": the same deferred join WITHOUT record_stream — the tensors the weight-gradient kernels read are simply kept
+# alive (a Python list) until the join at the end of backward, and released there, after the main stream has waited
+# for the side stream: no allocator events, at the price of every layer's dY staying allocated until backward ends
+DEFER_KEEPALIVE = os.environ.get("DTP_DEFER_JOIN", "0") == "2"
+_keepalive = []
 # ... but inside a hipGraph capture it is free: the captured step owns a private memory pool, nothing runs
 # ahead, and the data-gradient chain (the critical path of a launch-bound small-batch step) no longer waits
 # for each layer's weight gradient.  The per-bucket optimizer waits for both streams (parallel/reducer.py).
@@ -69,8 +74,11 @@ def _fork_wgrad(arena, device, *tensors):
     deferred = ((DEFER_JOIN or (GRAPH_DEFER_JOIN and torch.cuda.is_current_stream_capturing()))
                 and (arena.reducer is None or getattr(arena.reducer, "world", 1) == 1))
     if deferred:
-        for t in tensors:
-            t.record_stream(side)
+        if DEFER_KEEPALIVE and not torch.cuda.is_current_stream_capturing():
+            _keepalive.extend(tensors)
+        else:
+            for t in tensors:
+                t.record_stream(side)
         key = id(side)
         if key not in _pending_join:
             _pending_join[key] = side
@@ -78,6 +86,7 @@ def _fork_wgrad(arena, device, *tensors):
             def _join(side=side, key=key):
                 _pending_join.pop(key, None)
                 torch.cuda.current_stream().wait_stream(side)
+                del _keepalive[:]
             torch.autograd.Variable._execution_engine.queue_callback(_join)
     return side, deferred
 
