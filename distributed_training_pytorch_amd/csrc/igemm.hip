@@ -41,6 +41,11 @@ struct IgemmParams {
   const float* bn_shift;  //   (sum dyh, sum dyh*y) with dyh = dz * (y*scale + shift > 0)   [no mask when bn_scale is null]
   uint32_t* pool_codes;   // POOL kernels: `out` is the 2x2-max-pooled output [M/4][ldo], this the 4-bit codes [M/4][Ncols/8]
                           //   — the two reductions of the BatchNorm backward, which then skips its pass over (dz, y)
+  const uint32_t* unpool_codes;   // optional [M][Ncols/8] 4-bit codes of the 2x2 max-pool whose OUTPUT this GEMM's rows are the
+                          //   gradient of (a data gradient right above a pool): the epilogue routes every value to its
+                          //   arg-max position and `out` is the FULL-RESOLUTION gradient [N][2H][2W][ldo] — the pool
+                          //   backward kernel and the pooled gradient's round trip through HBM disappear
+  int unpool_relu;        //   ... and clears values whose code says "max <= 0" (the ReLU in front of the pool)
   int colsum_sq;          // colsum_part is [tiles_m][2][Ncols]: sums AND sums of squares — the batch
                           // statistics of a BatchNorm that follows this convolution (bn.hip partial layout)
   const char* zero_page;
@@ -819,6 +824,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
   }
 
   // ---------------- epilogue
+  // the un-pooling store loop exists in the 3x3 bf16 kernels only, and not in the two-stage / pipelined 256x256 ones
+  // (256 VGPRs and ~100 SGPRs already: its few extra kernel-uniform values made hipcc spill prologue values there)
+  constexpr bool UNPOOL = TAPS9 && !FP8 && !POOL && !(BM == 256 && BN == 256 && PIPE < 2);
   if (p.dq_a) {                        // kernel-uniform: fp8 dequantisation of the accumulators
     const float dq = p.dq_a[0] * p.dq_b[0];
 #pragma unroll
@@ -884,6 +892,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
 #pragma unroll
     for (int it = 0; it < ITER; ++it)
       mb[it] = __builtin_amdgcn_raw_buffer_load_b8(mb_rs, (int)(n_ok ? voff >> 4 : DTP_OOB_OFF), it * (row_step >> 4), 0);
+  } else if (UNPOOL && p.unpool_codes) {
+    // un-pooling: the 4-bit arg-max codes of this lane's chunks, 4 bytes per 16-byte chunk, in the same registers
+    const __amdgpu_buffer_rsrc_t cd_rs = make_rsrc((const char*)p.unpool_codes + (((size_t)m0 * p.ldo) >> 1), tile_bytes >> 2);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+      mb[it] = __builtin_amdgcn_raw_buffer_load_b32(cd_rs, (int)(n_ok ? voff >> 2 : DTP_OOB_OFF), it * (row_step >> 2), 0);
   }
   // raw barriers: hipcc's __syncthreads() waits vmcnt(0) first, which would expose the mask loads above
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1021,6 +1035,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     }
     const __amdgpu_buffer_rsrc_t o_rs = make_rsrc(p.out + (size_t)m0 * p.ldo * 2, tile_bytes);
     const bool unit_scale = p.mask_scale == 1.0f;      // kernel-uniform (every convolution)
+    // Un-pooling epilogue (p.unpool_codes, kernel-uniform): tile row m is the pooled pixel (img*H + oh)*W + ow whose 2x2
+    // window starts at pixel 4m - 2ow of the full-resolution gradient [N][2H][2W][ldo].  A lane walks rows G apart, so it
+    // carries (ow, byte offset of its window) from row to row instead of dividing per row; offsets are relative to the
+    // window of tile row 0 (the map m -> 4m - 2ow is monotonic, so they are >= 0 and < (4 BM + 2W) pixels).
+    __amdgpu_buffer_rsrc_t up_rs = o_rs;
+    unsigned up_off = 0;
+    int up_ow = 0, up_gm = 0;
+    uint32_t up_keep = 0, up_flip = 0;
+    if (UNPOOL && p.unpool_codes) {
+      const int ow_m0 = m0 % p.W;
+      up_ow = (m0 + pl0) % p.W;
+      up_gm = G % p.W;
+      const long base_px = 4l * m0 - 2l * ow_m0;
+      up_rs = make_rsrc(p.out + (size_t)base_px * p.ldo * 2, (4l * p.M - base_px) * p.ldo * 2);
+      up_off = (unsigned)((4 * pl0 - 2 * (up_ow - ow_m0)) * p.ldo + n) * 2u;
+      up_keep = p.unpool_relu ? 0x00070007u : 0x00030003u;     // code nibble: bits 1:0 arg-max, bit 2 "max > 0"
+      up_flip = p.unpool_relu ? 0x00040004u : 0u;              // bit 2 clear -> the value matches no window position
+    }
     constexpr int CH = ITER < 4 ? ITER : 4;     // rows per lane and pass: 4 LDS reads in flight, 4 stores back to back
     static_assert(ITER % CH == 0, "store loop chunking");
 #pragma unroll
@@ -1031,6 +1063,40 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       const int pl = pl0 + (c0 + it) * G;
       v[it] = *(const u32x4_t*)(smem + pl * (BN * 2) + ((q ^ (pl & 7)) << 4));
     }
+    if (UNPOOL && p.unpool_codes) {
+      typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+      typedef short s16x2_t __attribute__((ext_vector_type(2)));
+      const int row_b = p.ldo * 2, row_c = 2 * p.W * p.ldo * 2;      // (h, w+1) and (h+1, w) of the window, bytes
+#pragma unroll
+      for (int it = 0; it < CH; ++it) {
+        const int pl = pl0 + (c0 + it) * G;
+        const unsigned off = (n_ok && pl < rows_valid) ? up_off : DTP_OOB_OFF;
+        const uint32_t code = mb[c0 + it];
+        u32x4_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // both bf16 halves of a word at once: A = (arg-max | positive << 2) of channel 2e in the low half, of
+          // channel 2e+1 in the high half; half == k  <=>  (half ^ k) - 1 underflows  -> arithmetic >> 15 gives 0xFFFF
+          const uint32_t c8 = (code >> (8 * e)) & 0xFFu;
+          const uint32_t A = (((c8 << 12) | c8) & up_keep) ^ up_flip;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u16x2_t t = __builtin_bit_cast(u16x2_t, A ^ (uint32_t)(k * 0x00010001u)) - (u16x2_t){1, 1};
+            const uint32_t mk = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, t) >> (s16x2_t){15, 15});
+            o[k][e] = v[it][e] & mk;
+          }
+          v[it][e] = o[0][e] | o[1][e] | o[2][e] | o[3][e];       // what the column sums below see: the routed values
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o[0], up_rs, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[1], up_rs, (int)off, row_b, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[2], up_rs, (int)off, row_c, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o[3], up_rs, (int)off, row_c + row_b, 0);
+        int ow2 = up_ow + up_gm;
+        ow2 -= ow2 >= p.W ? p.W : 0;
+        up_off += (unsigned)((4 * G - 2 * (ow2 - up_ow)) * p.ldo * 2);
+        up_ow = ow2;
+      }
+    } else {
     if (p.mask_bits) {
 #pragma unroll
       for (int it = 0; it < CH; ++it) {
@@ -1079,6 +1145,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         const uint32_t b = bf16x2_pos_bits(x[0]) | (bf16x2_pos_bits(x[1]) << 2) | (bf16x2_pos_bits(x[2]) << 4) | (bf16x2_pos_bits(x[3]) << 6);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)b, bo_rs, (int)(n_ok ? voff >> 4 : DTP_OOB_OFF), (c0 + it) * (row_step >> 4), 0);
       }
+    }
     }
     if (p.colsum_part && p.bn_y) {       // kernel-uniform: BatchNorm-backward reductions of this dz tile
       const __amdgpu_buffer_rsrc_t by_rs = make_rsrc(p.bn_y + (size_t)m0 * p.ldo * 2, tile_bytes);
@@ -1207,7 +1274,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
                             int W, int lda, int ldb, int ldo, int out_fp32, int relu, float mask_scale,
                             float drop_p, unsigned long long seed, const void* seed_ptr, int fp8,
                             const float* dq_a, const float* dq_b, int colsum_sq, const void* bn_y,
-                            const float* bn_scale, const float* bn_shift, void* pool_codes, int nsplit, int cfg,
+                            const float* bn_scale, const float* bn_shift, void* pool_codes,
+                            const void* unpool_codes, int unpool_relu, int nsplit, int cfg,
                             hipStream_t stream) {
   // fp8 != 0: 8-bit operands, A [M][lda] (fp8 == 1: OCP e4m3, fp8 == 2: e5m2), B [Ncols][ldb] e4m3, bytes; K = C a multiple of 128
   if (M <= 0 || Ncols <= 0 || C <= 0 || (C & (fp8 ? 127 : 63))) return -10;   // K chunks are 128 bytes wide
@@ -1223,6 +1291,12 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.colsum_sq = colsum_part ? colsum_sq : 0;
   p.bn_y = (const char*)bn_y; p.bn_scale = bn_scale; p.bn_shift = bn_shift;
   p.pool_codes = (uint32_t*)pool_codes;
+  p.unpool_codes = (const uint32_t*)unpool_codes; p.unpool_relu = unpool_relu;
+  // un-pooling epilogue: 3x3 rows = pooled pixels, plain bf16 C-image store loop only (its offsets stay far below 2^31:
+  // a tile spans < 4*BM + 2W full-resolution pixels)
+  if (unpool_codes && (taps != 9 || out_fp32 || ldo != Ncols || mask_src || mask_bits || bits_out || bn_y || pool_codes ||
+                       fp8 || drop_p > 0.f || relu || bias || (long)(4 * 512 + 2 * (long)W + 8) * ldo * 2 > 0x3FFFFFFFl))
+    return -25;
   if ((cfg == 20 || cfg == 21) != (pool_codes != nullptr)) return -23;      // pooled output <-> pooling kernel
   if (bn_y && (!colsum_part || !colsum_sq || out_fp32 || (bn_scale && !bn_shift))) return -21;
   p.mask_bits = (const unsigned char*)mask_bits; p.bits_out = (unsigned char*)bits_out;
@@ -1243,6 +1317,7 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   nsplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
   if (nsplit > 1 && partial == nullptr) return -15;
   if (colsum_part && (nsplit > 1 || out_fp32)) return -17;   // only the bf16 C-image epilogue emits it
+  if (unpool_codes && (nsplit > 1 || cfg == 0 || cfg == 8)) return -25;
   if ((mask_bits || bits_out) && (nsplit > 1 || out_fp32)) return -20;   // 1-bit masks: same epilogue only
   int rc;
   const bool t9 = taps == 9;

@@ -181,6 +181,7 @@ bn_bwd_slot = _ColsumSlot()
 fuse_bn_stats = _os.environ.get("DTP_FUSE_BN_STATS", "1") != "0"      # A/B switch
 fuse_conv_pool = _os.environ.get("DTP_FUSE_CONV_POOL", "1") != "0"    # A/B switch
 fuse_igemm_pool = _os.environ.get("DTP_FUSE_IGEMM_POOL", "1") != "0"  # A/B switch: ... for the implicit-GEMM layers (blocks 2-5)
+fuse_unpool = _os.environ.get("DTP_FUSE_UNPOOL", "1") != "0"          # A/B switch: pool backward inside the data gradient above it
 fuse_colsum = True      # tests flip this to compare against the stand-alone column-sum kernel
 # conv2_1 dgrad as 2 conv_c64 passes: measured 640 vs 662 TF/s for the implicit GEMM at batch 256 and
 # no end-to-end difference (bench/bench_dgrad_c128.py, profiles/18_*): opt-in only
@@ -214,7 +215,10 @@ def bias_grad(dy2d, out, n_valid=None, beta=0.0):
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
            mask_scale, drop_p, seed, want_colsum=False, seed_ptr=None, fp8_scales=None, mask_bits=None,
-           bits_out=None, fp8_mode=1, want_bn_stats=False, bn_bwd_src=None, pool_codes=None):
+           bits_out=None, fp8_mode=1, want_bn_stats=False, bn_bwd_src=None, pool_codes=None, unpool=None):
+    """``unpool`` = (codes, relu_mask) of the 2x2 max-pool whose output these M rows are the gradient of:
+    ``out`` is then the full-resolution gradient [4*M][ldo] (csrc/igemm.hip, un-pooling epilogue).
+    Returns None instead when the chosen kernel cannot do it (split-K): the caller un-pools separately."""
     fp8 = fp8_scales is not None
     ksteps = taps * (C // (128 if fp8 else 64))
     if pool_codes is not None:
@@ -222,8 +226,8 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
         cfg = 20 if Ncols > 128 else 21
         rc = _lib.hip().dtp_igemm_nt(ptr(A), ptr(Bm), ptr(bias), None, None, None, ptr(out), None, None,
                                      ptr(workspace.zero_page(A.device)), M, Ncols, C, taps, H, W, lda, ldb, ldo, 0, 1,
-                                     1.0, 0.0, 0, None, 0, None, None, 0, None, None, None, ptr(pool_codes), 1, cfg,
-                                     stream())
+                                     1.0, 0.0, 0, None, 0, None, None, 0, None, None, None, ptr(pool_codes), None, 0,
+                                     1, cfg, stream())
         check(rc, "igemm_nt (conv + relu + pool)")
         return out
     cfg, nsplit = pick_igemm(M, Ncols, ksteps)
@@ -245,6 +249,8 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
             tiles = _cdiv(M, IGEMM_TILES[cfg][0]) * _cdiv(Ncols, IGEMM_TILES[cfg][1])
             if tiles < N_CU and ksteps >= 16:
                 nsplit = max(1, min(ksteps // 8, _cdiv(2 * N_CU, tiles)))
+    if unpool is not None and (nsplit > 1 or fp8 or out_fp32 or ldo != Ncols or cfg in (0, 8)):
+        return None
     partial = None
     if nsplit > 1:
         partial = workspace.get("igemm_partial", nsplit * M * Ncols, torch.float32, A.device)
@@ -284,7 +290,8 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
                                  int(out_fp32), int(relu), float(mask_scale), float(drop_p), int(seed) & (2 ** 64 - 1),
                                  ptr(seed_ptr), int(fp8_mode) if fp8 else 0, ptr(fp8_scales[0]) if fp8 else None,
                                  ptr(fp8_scales[1]) if fp8 else None, colsum_sq, ptr(bn_y), ptr(bn_sc), ptr(bn_sh),
-                                 None, nsplit, cfg, stream())
+                                 None, ptr(unpool[0]) if unpool is not None else None,
+                                 int(bool(unpool[1])) if unpool is not None else 0, nsplit, cfg, stream())
     check(rc, "igemm_nt")
     return out
 
@@ -392,17 +399,33 @@ def split_dgrad_weight(wd, Cin, Co):
     return (w3[:, :, :64].contiguous().view(Cin, 9 * 64), w3[:, :, 64:128].contiguous().view(Cin, 9 * 64))
 
 
-def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None, wd_halves=None, bn_bwd_src=None):
+def conv3x3_dgrad(dy, wd, mask_src=None, mask_scale=1.0, out=None, mask_bits=None, wd_halves=None, bn_bwd_src=None,
+                  unpool=None):
     """dx = conv3x3_same(dy, wd) [* (mask_src > 0)]; wd is the dgrad-layout weight [Cin, 9*Cout].
     ``mask_bits`` (from ``conv3x3_fprop(..., want_bits=True)`` of the layer that produced
     ``mask_src``) replaces the 2-byte-per-element mask read by 1 bit per element.
     ``bn_bwd_src`` = (y, stats, relu) of the training-mode BatchNorm(+ReLU) whose OUTPUT this
     convolution consumed: dx is that BatchNorm's dz, and the kernel leaves the two reductions of
-    its backward pass behind (``bn_bwd_slot``)."""
+    its backward pass behind (``bn_bwd_slot``).
+    ``unpool`` = (codes, relu_mask): the convolution's input was the output of a 2x2 max-pool with
+    those forward codes; the result is the gradient of the pool's INPUT, [N, 2H, 2W, Cin], with its
+    column sums left behind — or None when this shape has no fused path (caller: plain dgrad, then
+    :func:`maxpool2x2_bwd`)."""
     _need(dy, BF16, "dy")
     _need(wd, BF16, "wd")
     N, H, W, Co = dy.shape
     Cin = wd.shape[0]
+    if unpool is not None:
+        codes, relu_mask = unpool
+        if (not fuse_unpool or mask_src is not None or out is not None or (Co == 64 and "igemm" not in _overrides)
+                or (Co == 128 and Cin == 64 and two_pass_c128 and "igemm" not in _overrides)
+                or wd.numel() != Cin * 9 * Co or Co % 64 or Cin % 8):
+            return None
+        if codes.dtype != torch.int32 or not codes.is_contiguous() or tuple(codes.shape) != (N, H, W, Cin // 8):
+            raise ValueError("conv3x3_dgrad: unpool codes shape %s" % (tuple(codes.shape),))
+        full = torch.empty((N, 2 * H, 2 * W, Cin), dtype=BF16, device=dy.device)
+        return _igemm(dy, wd, None, None, full, N * H * W, Cin, Co, 9, H, W, Co, 9 * Co, Cin, False, False,
+                      1.0, 0.0, 0, want_colsum=True, unpool=(codes, relu_mask))
     if wd.numel() != Cin * 9 * Co or Co % 64 or Cin % 8:
         raise ValueError("conv3x3_dgrad: bad shapes dy=%s wd=%s" % (tuple(dy.shape), tuple(wd.shape)))
     if mask_src is not None:

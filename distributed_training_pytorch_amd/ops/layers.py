@@ -122,6 +122,55 @@ def _arena_of(layer):
     return a
 
 
+class _PoolLink(object):
+    """Hand-over between a 2x2 max-pool and the convolution that consumes its output.
+
+    Forward: the pool hangs one of these on its output tensor (``_dtp_pool_link``) and the next
+    Conv3x3 keeps it.  Backward: that convolution's data-gradient kernel routes every value to its
+    arg-max position itself (csrc/igemm.hip, un-pooling epilogue) and parks the FULL-RESOLUTION
+    gradient here; what it returns to autograd is a stride-0 placeholder of the pooled shape.  The
+    pool's backward takes the parked tensor instead of running the pool-backward kernel — after
+    checking that the gradient it was handed is that very placeholder (a second consumer of the
+    pooled activation would make autograd sum into a fresh tensor, which is refused loudly)."""
+
+    __slots__ = ("codes", "in_shape", "relu_mask", "full", "token")
+
+    def __init__(self, codes, in_shape, relu_mask):
+        self.codes, self.in_shape, self.relu_mask = codes, tuple(in_shape), bool(relu_mask)
+        self.full = None
+        self.token = None
+
+    def park(self, full, pooled_shape):
+        self.full = full
+        self.token = full.as_strided(tuple(pooled_shape), (0,) * len(pooled_shape))
+        return self.token
+
+    def take(self, dyp):
+        """The parked full-resolution gradient if ``dyp`` is this link's placeholder, else None."""
+        full, token = self.full, self.token
+        self.full = self.token = None
+        if full is None:
+            return None
+        if dyp.data_ptr() != token.data_ptr() or dyp.stride() != token.stride() or dyp.shape != token.shape:
+            raise RuntimeError("un-pooled gradient hand-over: the pooled activation has more than one consumer "
+                               "(or a hook rewrote its gradient); run with DTP_FUSE_UNPOOL=0")
+        return full
+
+
+def _dgrad_through_pool(link, x, dy, wd):
+    """Data gradient of a convolution whose input ``x`` is ``link``'s pool output, un-pooled in the
+    same kernel; None when there is no fused path for this shape."""
+    if link is None or not K.fuse_unpool:
+        return None
+    N, H, W, C = x.shape
+    if link.in_shape != (N, 2 * H, 2 * W, C):
+        return None
+    full = K.conv3x3_dgrad(dy, wd, unpool=(link.codes, link.relu_mask))
+    if full is None:
+        return None
+    return link.park(full, x.shape)
+
+
 class FusedLayer(nn.Module):
     """Base: access to the arena's bf16 weight copy and lazily derived dgrad layouts."""
 
@@ -185,6 +234,8 @@ class _Conv3x3Fn(torch.autograd.Function):
         # x is the output of a training-mode BatchNorm(+ReLU): (its input y, its statistics, relu) — this
         # layer's data gradient then leaves that BatchNorm's backward reductions behind
         ctx.bn_src = getattr(x, "_dtp_bn_src", None)
+        # x is the output of a 2x2 max-pool: the data gradient un-pools in its epilogue (see _PoolLink)
+        ctx.pool_link = getattr(x, "_dtp_pool_link", None) if not layer.input_is_relu_out else None
         ctx.save_for_backward(x, y, weight, bias)
         return y
 
@@ -219,8 +270,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             Ci = weight.shape[1]
             arena.wait_derived()
             wd = layer._cached("wd", lambda: K.conv_weight_to_dgrad(arena.lp(weight), Co, Ci))
-            dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
-                                 wd_halves=layer._wd_halves(wd), bn_bwd_src=ctx.bn_src)
+            dx = _dgrad_through_pool(ctx.pool_link, x, dy, wd) if ctx.bn_src is None else None
+            if dx is None:
+                dx = K.conv3x3_dgrad(dy, wd, mask_src=x if layer.input_is_relu_out else None, mask_bits=ctx.mask_bits,
+                                     wd_halves=layer._wd_halves(wd), bn_bwd_src=ctx.bn_src)
         if late:
             with torch.cuda.stream(side):
                 K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
@@ -243,6 +296,8 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         y, codes = K.conv3x3_relu_pool_fprop(x, arena.lp(weight), bias.detach())
         ctx.layer = layer
         ctx.mask_bits = getattr(x, "_dtp_relu_bits", None) if (K.relu_bitmask and layer.input_is_relu_out) else None
+        ctx.pool_link = _PoolLink(codes, (x.shape[0], x.shape[1], x.shape[2], weight.shape[0]), True)
+        layer.__dict__["_link_tmp"] = ctx.pool_link
         ctx.save_for_backward(x, codes, weight, bias)
         return y
 
@@ -253,7 +308,9 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         x, codes, weight, bias = ctx.saved_tensors
         N, H, W, _ = x.shape
         Co, Ci = weight.shape[0], weight.shape[1]
-        dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
+        dy = ctx.pool_link.take(dyp)        # the consumer's data gradient may have un-pooled already
+        if dy is None:
+            dy = K.maxpool2x2_bwd(None, dyp.contiguous(), relu_mask=True, idx=codes, in_shape=(N, H, W, Co))
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
         late = side is not None and _record_late()
@@ -291,7 +348,11 @@ def conv_relu_pool(conv, x):
         return None
     if not K.conv_pool_fusable(x.shape[3], conv.out_channels, x.shape[1], x.shape[2], N=x.shape[0]):
         return None
-    return _Conv3x3ReluPoolFn.apply(x, conv.weight, conv.bias, conv)
+    y = _Conv3x3ReluPoolFn.apply(x, conv.weight, conv.bias, conv)
+    link = conv.__dict__.pop("_link_tmp", None)
+    if link is not None and torch.is_grad_enabled():
+        y._dtp_pool_link = link          # travels with the pooled activation to the next Conv3x3
+    return y
 
 
 class _Conv3x3Derived(object):
@@ -456,12 +517,17 @@ class _MaxPoolFn(torch.autograd.Function):
         y, idx = K.maxpool2x2_fwd(x, want_idx=True)
         ctx.relu_mask = relu_mask
         ctx.in_shape = tuple(x.shape)
+        ctx.pool_link = _PoolLink(idx, ctx.in_shape, relu_mask) if (x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0) else None
+        _MaxPoolFn.last_link = ctx.pool_link
         ctx.save_for_backward(idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
+        full = ctx.pool_link.take(dy) if ctx.pool_link is not None else None
+        if full is not None:
+            return full, None
         return K.maxpool2x2_bwd(None, dy.contiguous(), relu_mask=ctx.relu_mask, idx=idx,
                                 in_shape=ctx.in_shape), None
 
@@ -477,7 +543,11 @@ class MaxPool2x2(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             return F.max_pool2d(x, 2, 2)
-        return _MaxPoolFn.apply(x, self.relu_mask)
+        y = _MaxPoolFn.apply(x, self.relu_mask)
+        link, _MaxPoolFn.last_link = getattr(_MaxPoolFn, "last_link", None), None
+        if link is not None and torch.is_grad_enabled() and y.requires_grad:
+            y._dtp_pool_link = link
+        return y
 
 
 class _AvgPoolFlattenFn(torch.autograd.Function):

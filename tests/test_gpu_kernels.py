@@ -1303,3 +1303,53 @@ def test_wgrad_8phase_linear_form_is_bit_identical():
         assert torch.equal(outs[0], outs[1]), (B, Nout, Kin, ns)
         ref = dy[:, :Nout].float().t() @ x.float()
         _close(outs[1], ref, 2e-2, 2e-2 * ref.abs().max().item(), "linear wgrad 8-phase")
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 11, 16, 17, 18, 19])
+@pytest.mark.parametrize("relu_mask", [True, False])
+def test_dgrad_unpools_in_its_epilogue_bit_for_bit(cfg, relu_mask):
+    """conv3x3_dgrad(unpool=...) == maxpool2x2_bwd(conv3x3_dgrad(...)) bit for bit, for every tile
+    shape of the implicit GEMM, with image rows that wrap inside a lane's row stride (W = 10 < G),
+    a row tail in every tile size, and the column sums of the routed values left behind."""
+    k = _k()
+    torch.manual_seed(21)
+    N, H, W, C, Co = 3, 18, 10, 192, 128           # pooled map 18x10 (M = 540), pool input 36x20
+    if cfg == 18:
+        k.igemm_shared_a = True
+    xin = _rand(N, 2 * H, 2 * W, C)                 # the pool's input: about half of the maxima are <= 0
+    _, codes = k.maxpool2x2_fwd(xin, want_idx=True)
+    dy = _rand(N, H, W, Co)
+    wd = _rand(C, 9 * Co, scale=(2.0 / (9 * Co)) ** 0.5)
+    k._overrides["igemm"] = lambda M, Nc, ks: (cfg, 1)
+    try:
+        full = k.conv3x3_dgrad(dy, wd, unpool=(codes, relu_mask))
+        assert full is not None and tuple(full.shape) == (N, 2 * H, 2 * W, C)
+        assert k.colsum_slot.tensor is full
+        bias_g = torch.empty(C, device="cuda")
+        k.bias_grad(full.view(-1, C), bias_g)
+        dxp = k.conv3x3_dgrad(dy, wd)
+    finally:
+        k._overrides.pop("igemm")
+    ref = k.maxpool2x2_bwd(None, dxp, relu_mask=relu_mask, idx=codes, in_shape=(N, 2 * H, 2 * W, C))
+    k.colsum_slot.take(ref, C)
+    assert torch.equal(full, ref), "cfg %d: %d elements differ" % (cfg, (full != ref).sum().item())
+    _close(bias_g, ref.float().view(-1, C).sum(0), 1e-5, 1e-3, "un-pooled colsum cfg%d" % cfg)
+
+
+def test_dgrad_unpool_declines_what_it_cannot_do():
+    k = _k()
+    N, H, W, C, Co = 2, 8, 8, 64, 128
+    dy, wd = _rand(N, H, W, Co), _rand(C, 9 * Co)
+    codes = torch.zeros((N, H, W, C // 8), dtype=torch.int32, device="cuda")
+    k._overrides["igemm"] = lambda M, Nc, ks: (3, 2)            # split-K: no bf16 C-image epilogue
+    try:
+        assert k.conv3x3_dgrad(dy, wd, unpool=(codes, True)) is None
+    finally:
+        k._overrides.pop("igemm")
+    k.fuse_unpool = False
+    try:
+        assert k.conv3x3_dgrad(dy, wd, unpool=(codes, True)) is None
+    finally:
+        k.fuse_unpool = True
+    with pytest.raises(ValueError):
+        k.conv3x3_dgrad(dy, wd, unpool=(codes[:, :4], True))

@@ -425,6 +425,81 @@ def test_relu_bitmask_model_gradients_bit_identical():
         K._overrides.pop("igemm", None)
 
 
+def test_unpooling_data_gradient_model_gradients_bit_identical():
+    """Whole model: with the pool backward folded into the data gradient of the convolution above it
+    (DTP_FUSE_UNPOOL A/B switch) every gradient is bit-identical to the separate pool-backward
+    kernel, the four pools between convolutions really took the fused path, and a second consumer
+    of a pooled activation is refused instead of producing a wrong sum."""
+    from distributed_training_pytorch_amd.ops import kernels as K
+    from distributed_training_pytorch_amd.ops import layers as L
+    _, gpu = _models(seed=12)
+    gpu.eval()                                   # dropout off: both runs see the same masks
+    a = gpu.param_arena
+    crit = L.SoftmaxCrossEntropy()
+    torch.manual_seed(13)
+    x = torch.randn(8, 3, 64, 64, device="cuda")
+    y = torch.randint(0, 3, (8,), device="cuda")
+    pool_bwd_calls = []
+    orig = K.maxpool2x2_bwd
+
+    def spy(*args, **kw):
+        pool_bwd_calls.append(tuple(kw.get("in_shape") or ()))
+        return orig(*args, **kw)
+
+    def run():
+        a.zero_grad()
+        crit(gpu(x), y).backward()
+        torch.cuda.synchronize()
+        return {n: a.grad(p).clone() for n, p in gpu.named_parameters()}
+
+    def same(g1, g2):
+        # weight gradients bit for bit; a bias gradient is a column sum whose f32 partial rows now come from
+        # the GEMM's tiles instead of the pool kernel's blocks: same addends, another order
+        for n in g1:
+            if n.endswith("bias"):
+                torch.testing.assert_close(g1[n], g2[n], rtol=1e-4, atol=1e-5 * max(1.0, g2[n].abs().max().item()), msg=n)
+            else:
+                assert torch.equal(g1[n], g2[n]), n
+
+    K.maxpool2x2_bwd = spy
+    K._overrides["igemm"] = lambda M, Nc, ks: (3, 1)      # single-pass tiles (tiny grids would take split-K)
+    try:
+        assert K.fuse_unpool
+        fused = run()
+        n_fused = len(pool_bwd_calls)
+        K.fuse_unpool = False
+        del pool_bwd_calls[:]
+        plain = run()
+        n_plain = len(pool_bwd_calls)
+        K.fuse_unpool = True
+        assert n_plain == 5 and n_fused == 1, (n_plain, n_fused)      # only the pool under the classifier stays a kernel
+        same(fused, plain)
+        # the shipped picker on this tiny grid: whatever mix of fused / separate it chooses, same bits
+        K._overrides.pop("igemm")
+        shipped = run()
+        K.fuse_unpool = False
+        same(shipped, run())
+    finally:
+        K.fuse_unpool = True
+        K.maxpool2x2_bwd = orig
+        K._overrides.pop("igemm", None)
+
+    # a pooled activation with two consumers: autograd sums the placeholder with the other gradient
+    from distributed_training_pytorch_amd.models.fused_model import attach_arena
+    conv = L.Conv3x3(64, 128).cuda()
+    attach_arena(conv)
+    pool = L.MaxPool2x2(relu_mask=True)
+    xin = torch.randn(2, 16, 16, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    K._overrides["igemm"] = lambda M, Nc, ks: (3, 1)
+    try:
+        p = pool(xin)
+        out = conv(p).float().sum() + p.float().sum()
+        with pytest.raises(RuntimeError, match="more than one consumer"):
+            out.backward()
+    finally:
+        K._overrides.pop("igemm", None)
+
+
 def test_no_uninitialised_reads_with_poisoned_allocator():
     """Every free block of the caching allocator (large and small pools) and every persistent
     workspace is filled with NaN before each step: a kernel that consumes memory neither it nor its
