@@ -192,25 +192,38 @@ igemm_shared_a_n128 = _os.environ.get("DTP_IGEMM_SHARED_A_N128", "1") != "0"   #
 relu_bitmask = _os.environ.get("DTP_RELU_BITMASK", "1") != "0"        # A/B switch: 1-bit ReLU masks for dgrad
 
 
-def colsum_parts(parts, nparts, C, out, n_valid=None, beta=0.0):
+_cs_parts_flip = [0]
+
+
+def _colsum_parts_workspace(numel, device):
+    """Partial-row buffer for the next producer: two buffers, used alternately.  The rows a producer leaves are
+    reduced by the bias gradient of the NEXT backward function, which may run on the weight-gradient side stream
+    while that function's own data gradient (the next producer) is already writing: it writes the other buffer,
+    and the side stream is joined before the function after that starts."""
+    _cs_parts_flip[0] ^= 1
+    return workspace.get("colsum_parts%d" % _cs_parts_flip[0], numel, torch.float32, device)
+
+
+def colsum_parts(parts, nparts, C, out, n_valid=None, beta=0.0, ws_key="colsum"):
     """out[:n_valid] = beta*out + sum of the producer's partial rows parts[nparts][C]."""
     nv = C if n_valid is None else n_valid
     if out.numel() != nv or out.dtype not in (torch.float32, BF16) or parts.numel() < nparts * C:
         raise ValueError("colsum_parts: bad shapes")
-    ws = workspace.get("colsum", 1024 * max(C, 64), torch.float32, parts.device)
+    ws = workspace.get(ws_key, 1024 * max(C, 64), torch.float32, parts.device)
     rc = _lib.hip().dtp_colsum_parts(ptr(parts), nparts, C, nv, ptr(out), ptr(ws), ws.numel(),
                                      int(out.dtype == torch.float32), float(beta), stream())
     check(rc, "colsum_parts")
     return out
 
 
-def bias_grad(dy2d, out, n_valid=None, beta=0.0):
+def bias_grad(dy2d, out, n_valid=None, beta=0.0, ws_key="colsum"):
     """Bias gradient = column sums of dY: from the producer's partial rows when the kernel that
-    wrote dY left them (see _ColsumSlot), else with the two-pass column-sum kernel."""
+    wrote dY left them (see _ColsumSlot), else with the two-pass column-sum kernel.  ``ws_key``: scratch
+    buffer name — a caller on a side stream passes its own so that it shares nothing with the main stream."""
     got = colsum_slot.take(dy2d, dy2d.shape[-1]) if fuse_colsum else None
     if got is not None:
-        return colsum_parts(got[0], got[1], dy2d.shape[-1], out, n_valid, beta)
-    return colsum(dy2d, out, n_valid, beta)
+        return colsum_parts(got[0], got[1], dy2d.shape[-1], out, n_valid, beta, ws_key=ws_key)
+    return colsum(dy2d, out, n_valid, beta, ws_key=ws_key)
 
 
 def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, out_fp32, relu,
@@ -257,7 +270,7 @@ def _igemm(A, Bm, bias, mask_src, out, M, Ncols, C, taps, H, W, lda, ldb, ldo, o
     cs_part = None
     if want_colsum and fuse_colsum and nsplit == 1 and not out_fp32 and ldo == Ncols:
         nparts = _cdiv(M, IGEMM_TILES[cfg][0])
-        cs_part = workspace.get("colsum_parts", nparts * Ncols, torch.float32, A.device)
+        cs_part = _colsum_parts_workspace(nparts * Ncols, A.device)
         colsum_slot.put(out, cs_part, nparts, Ncols)
     colsum_sq = 0
     if (want_bn_stats and fuse_bn_stats and cs_part is None and nsplit == 1 and not out_fp32 and ldo == Ncols
@@ -594,14 +607,14 @@ def linear_wgrad(dy, x, out, n_valid=None, beta=0.0):
     return _wgrad(dy, x, out, M, Nout, K, K, 1, 1, 1, ld, K, beta)
 
 
-def colsum(x2d, out, n_valid=None, beta=0.0):
+def colsum(x2d, out, n_valid=None, beta=0.0, ws_key="colsum"):
     """out[:n_valid] = beta*out + column sums of x2d [rows, C] (bias gradient)."""
     _need(x2d, BF16, "x2d")
     rows, C = x2d.shape
     nv = C if n_valid is None else n_valid
     if C % 8 or out.numel() != nv or out.dtype not in (torch.float32, BF16):
         raise ValueError("colsum: bad shapes")
-    ws = workspace.get("colsum", 1024 * max(C, 64), torch.float32, x2d.device)
+    ws = workspace.get(ws_key, 1024 * max(C, 64), torch.float32, x2d.device)
     rc = _lib.hip().dtp_colsum(ptr(x2d), ptr(out), ptr(ws), ws.numel(), rows, C, nv, C,
                                int(out.dtype == torch.float32), float(beta), stream())
     check(rc, "colsum")
@@ -640,7 +653,7 @@ def maxpool2x2_bwd(x, dy, relu_mask=False, idx=None, in_shape=None):
     if fuse_colsum and 256 % (C // 8) == 0 and H % 2 == 0 and W % 2 == 0:
         # dx is the dY of the convolution that produced x: leave its column sums behind
         max_parts = 1024
-        cs_part = workspace.get("colsum_parts", max_parts * C, torch.float32, dy.device)
+        cs_part = _colsum_parts_workspace(max_parts * C, dy.device)
     nparts = _ctypes.c_int(0)
     check(_lib.hip().dtp_maxpool2x2_bwd(ptr(x), ptr(idx), ptr(dy), ptr(dx), N, H, W, C, int(relu_mask),
                                         ptr(cs_part), max_parts, _ctypes.byref(nparts), stream()), "maxpool_bwd")

@@ -38,6 +38,10 @@ FP8_DGRAD = os.environ.get("DTP_FP8_DGRAD", "1") == "1"     # A/B switch: fp8 la
 # order of a node's out-edges decides which child the ROCm graph executor keeps on the parent's stream: with
 # the data gradient recorded first the backward chain stays on one hardware queue and the side work hops.
 GRAPH_MAIN_FIRST = os.environ.get("DTP_GRAPH_MAIN_FIRST", "1") == "1"
+# opt-in: the bias gradient of a convolution issued behind its weight gradient on the side stream instead of in
+# front of the data gradient.  Measured -0.3 to -0.6 % at batch 1024 (three same-box pairs): the two tiny kernels
+# cost less in the gap in front of the data gradient than as a tail on the weight-gradient chain
+BIAS_GRAD_ON_SIDE = os.environ.get("DTP_BIAS_GRAD_ON_SIDE", "0") == "1"
 _side_streams = {}
 
 
@@ -99,7 +103,7 @@ def _side_stream(device):
     return s
 
 
-def _bias_grad(layer, arena, dy2d, bias):
+def _bias_grad(layer, arena, dy2d, bias, ws_key="colsum"):
     """Bias gradient of a convolution = column sums of its dY.  When a training-mode BatchNorm
     follows the convolution, dY comes out of the BatchNorm backward and its column sums are zero by
     construction (sum_rows dY = g * (S1 - M*c1 - c2 * sum_rows xhat) with c1 = S1/M and
@@ -110,7 +114,7 @@ def _bias_grad(layer, arena, dy2d, bias):
         if beta == 0.0:
             arena.grad(bias).zero_()
         return
-    K.bias_grad(dy2d, arena.grad(bias), beta=beta)
+    K.bias_grad(dy2d, arena.grad(bias), beta=beta, ws_key=ws_key)
 
 
 def _arena_of(layer):
@@ -251,6 +255,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
         late = side is not None and _record_late()
+        bias_done = False
         if side is not None:
             # weight gradient on a second stream, concurrent with the data gradient below: both
             # read dY, neither reads the other's output, and the tail of one kernel's last round of
@@ -259,11 +264,16 @@ class _Conv3x3Fn(torch.autograd.Function):
             if not late:
                 with torch.cuda.stream(side):
                     K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
+                    if ctx.has_bias and BIAS_GRAD_ON_SIDE:
+                        # the bias gradient (a reduction of the partial rows dY's producer left) rides behind the
+                        # weight gradient: two tiny kernels less per layer on the data-gradient chain
+                        _bias_grad(layer, arena, dy.view(-1, Co), bias, ws_key="colsum_side")
+                        bias_done = True
                 if K.wgrad_is_persistent(x.shape[3], Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
                     K.stream_delay(K.wgrad_head_start_us)     # the persistent grid must be resident first
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-        if ctx.has_bias:
+        if ctx.has_bias and not bias_done:
             _bias_grad(layer, arena, dy.view(-1, Co), bias)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -314,16 +324,21 @@ class _Conv3x3ReluPoolFn(torch.autograd.Function):
         side, deferred = (_fork_wgrad(arena, dy.device, dy, x) if (OVERLAP_WGRAD and ctx.needs_input_grad[0])
                           else (None, False))
         late = side is not None and _record_late()
+        bias_done = False
         if side is not None:
             beta_w = arena.grad_beta(weight)
             if not late:
                 with torch.cuda.stream(side):
                     K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=beta_w)
+                    if BIAS_GRAD_ON_SIDE:
+                        K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias), ws_key="colsum_side")
+                        bias_done = True
                 if K.wgrad_is_persistent(Ci, Co) and dy.numel() >= K.WGRAD_HEAD_START_MIN_ELEMS:
                     K.stream_delay(K.wgrad_head_start_us)
         else:
             K.conv3x3_wgrad(dy, x, arena.grad(weight), beta=arena.grad_beta(weight))
-        K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
+        if not bias_done:
+            K.bias_grad(dy.view(-1, Co), arena.grad(bias), beta=arena.grad_beta(bias))
         dx = None
         if ctx.needs_input_grad[0]:
             arena.wait_derived()
