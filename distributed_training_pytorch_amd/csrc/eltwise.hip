@@ -144,29 +144,43 @@ extern "C" int dtp_colsum(const void* x, void* out, float* workspace, int ws_flo
 // f32 variant of pass 1 for partial rows emitted by producer epilogues (igemm / maxpool backward)
 __global__ void colsum_f32_pass1_kernel(const float* __restrict__ part_in, float* __restrict__ part, int rows, int C,
                                         int rpb) {
-  const int lanes = C < 256 ? C : 256;
+  // C % 4 == 0 (the producers emit C % 8 == 0): a thread owns four adjacent columns (16-byte loads) and walks its
+  // rows four at a time into four independent accumulators — the first version (4-byte loads, one accumulator chain
+  // per thread, 128 workgroups) averaged 36.5 us over the twelve bias gradients of a batch-1024 step (33-50 k partial
+  // rows behind the data gradients of the 112 x 112 layers), this one 18.6; a fixed summation order either way
+  const int c4n = C >> 2;
+  const int lanes = c4n < 256 ? c4n : 256;
   const int rr_n = 256 / lanes;
   const int cl = threadIdx.x % lanes, rr = threadIdx.x / lanes;
   const int r0 = blockIdx.x * rpb;
   int r1 = r0 + rpb; if (r1 > rows) r1 = rows;
-  __shared__ float red[256];
-  for (int c0 = 0; c0 < C; c0 += lanes) {
+  __shared__ f32x4_t red[256];
+  const f32x4_t* in4 = (const f32x4_t*)part_in;
+  for (int c0 = 0; c0 < c4n; c0 += lanes) {
     const int c = c0 + cl;
-    float acc = 0.f;
-    if (c < C && rr < rr_n)
-      for (int r = r0 + rr; r < r1; r += rr_n) acc += part_in[(size_t)r * C + c];
+    f32x4_t a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (c < c4n && rr < rr_n) {
+      int r = r0 + rr;
+      for (; r + 3 * rr_n < r1; r += 4 * rr_n) {
+        const f32x4_t v0 = in4[(size_t)r * c4n + c], v1 = in4[(size_t)(r + rr_n) * c4n + c];
+        const f32x4_t v2 = in4[(size_t)(r + 2 * rr_n) * c4n + c], v3 = in4[(size_t)(r + 3 * rr_n) * c4n + c];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+      }
+      for (; r < r1; r += rr_n) a0 += in4[(size_t)r * c4n + c];
+    }
+    f32x4_t acc = (a0 + a1) + (a2 + a3);
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (rr == 0 && c < C) {
+    if (rr == 0 && c < c4n) {
       for (int k = 1; k < rr_n; ++k) acc += red[k * lanes + cl];
-      part[(size_t)blockIdx.x * C + c] = acc;
+      ((f32x4_t*)part)[(size_t)blockIdx.x * c4n + c] = acc;
     }
     __syncthreads();
   }
 }
 
 // out[:Cvalid] = beta*out + sum_r part_in[r][:]; part_in [nparts][C] f32 written by a producer's
-// epilogue; workspace >= 128*C floats (used when nparts > 128)
+// epilogue; workspace >= 256*C floats for the full grid (used when nparts > 128)
 extern "C" int dtp_colsum_parts(const float* part_in, int nparts, int C, int Cvalid, void* out, float* workspace,
                                 int ws_floats, int out_fp32, float beta, hipStream_t s) {
   if (nparts <= 0 || C <= 0 || Cvalid > C) return -10;
@@ -174,7 +188,8 @@ extern "C" int dtp_colsum_parts(const float* part_in, int nparts, int C, int Cva
   int nb = nparts;
   if (nparts > 128) {
     nb = ws_floats / C;
-    if (nb > 128) nb = 128;
+    if (nb > 256) nb = 256;
+    if (C & 3) return -12;
     if (nb < 1) return -11;
     const int rpb = (nparts + nb - 1) / nb;
     nb = (nparts + rpb - 1) / rpb;
