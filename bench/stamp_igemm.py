@@ -10,9 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BF16 = torch.bfloat16
 N_IMG, HW, C, Co = int(os.environ.get("N", "256")), int(os.environ.get("HW", "56")), int(os.environ.get("C", "256")), int(os.environ.get("CO", "256"))
 CFG = int(os.environ.get("CFG", "16"))
-BM = 512 if CFG == 17 else 256
+BM, BN = {17: (512, 128), 19: (384, 128)}.get(CFG, (256, 256))
 M = N_IMG * HW * HW
-BN = 128 if CFG in (17, 18) else 256
 tiles = (M + BM - 1) // BM * ((Co + BN - 1) // BN)
 stamps = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
 os.environ["DTP_IGEMM_STAMPS"] = hex(stamps.data_ptr())

@@ -64,6 +64,9 @@ struct IgemmParams {
   int ksteps_total;
   int ksteps_per_split;
   int tiles_m, tiles_n;
+  int pf_rows;            // PIPE 3, not POOL: the image loads past the last super-tile (issued anyway to keep the counted
+                          // waits uniform) read super-tile 0 of the tile pf_rows rows further down — the tile this XCD
+                          // starts next — so that its prologue finds the rows in L2; 0 = off
   int k_order;            // 3x3 reduction order: 0 = tap-major (tap, channel chunk), 1 = chunk-major (chunk, tap)
   unsigned long long* stamps;   // DEBUG (DTP_IGEMM_STAMPS): per workgroup {hw_id|xcc, t_entry, t_loop, t_loop_end, t_exit}
 };
@@ -780,8 +783,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
       // (loads issued for super-tiles >= NS at the tail read in-range garbage or hardware zeros into
       // slots nobody reads any more; they only keep the counted waits uniform)
       const unsigned kb0 = kb_of(S), kb1 = kb_of(S + 1), kb2 = kb_of(S + 2);
-      const unsigned si1 = si_of(S + 1), si2 = si_of(S + 2);
-      const int dy1 = dy_of(S + 1), dy2 = dy_of(S + 2);
+      const bool pf = !POOL && p.pf_rows > 0 && S + 2 >= NS;      // last iteration: prefetch for the XCD's next tile
+      const unsigned si1 = si_of(S + 1), si2 = pf ? (unsigned)p.pf_rows * c2 : si_of(S + 2);
+      const int dy1 = dy_of(S + 1), dy2 = pf ? 0 : dy_of(S + 2);
       DTP3_SUPER(0, 0, kb0, kb1, si1, dy1)         // K-tiles 3S .. 3S+2   (B dbuf 0, 1, 0)
       DTP3_SUPER(1, 1, kb1, kb2, si2, dy2)         // K-tiles 3S+3 .. 3S+5 (B dbuf 1, 0, 1)
     }
@@ -1307,6 +1311,8 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
   p.a_bf8 = fp8 == 2;
   static const int k_order_env = std::getenv("DTP_IGEMM_KORDER") ? std::atoi(std::getenv("DTP_IGEMM_KORDER")) : 1;
   p.k_order = k_order_env;
+  static const int pf_env = std::getenv("DTP_IGEMM_PREFETCH_NEXT") ? std::atoi(std::getenv("DTP_IGEMM_PREFETCH_NEXT")) : 1;
+  p.pf_rows = 0;      // set per configuration below
   p.stamps = nullptr;
   if (const char* e = std::getenv("DTP_IGEMM_STAMPS")) p.stamps = (unsigned long long*)std::strtoull(e, nullptr, 0);
   if (fp8 && (!dq_a || !dq_b)) return -19;
@@ -1347,10 +1353,12 @@ extern "C" int dtp_igemm_nt(const void* A, const void* B, const float* bias, con
     case 17: rc = DTP_IG(512, 128, 4, 2, 2); break;   // 8-phase for outputs of <= 128 channels
     case 18:        // 8-phase over one staged activation image per tap row (3x3 only, C % 128 == 0, no split-K)
       if (!t9 || nsplit != 1 || (C & 127)) return -22;
+      if (pf_env) p.pf_rows = (32 / ((Ncols + 255) / 256 > 32 ? 32 : (Ncols + 255) / 256)) * 256;
       rc = launch_cfg<256, 256, 2, 4, true, 3>(p, nsplit, stream);
       break;
     case 19:        // the same schedule as a 384x128 tile (4x2 waves of 96x64) for outputs of <= 128 channels
       if (!t9 || nsplit != 1 || (C & 127)) return -22;
+      if (pf_env) p.pf_rows = 32 * 384;
       rc = launch_cfg<384, 128, 4, 2, true, 3>(p, nsplit, stream);
       break;
     case 20: case 21:   // cfg 18 / 19 + ReLU + 2x2 max-pool in the epilogue: `out` is the POOLED tensor [M/4][ldo]
