@@ -656,20 +656,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     auto dy_of = [&](int S) -> int { return S - (S / 3) * 3; };
     // ---- fragment read addresses: image row of tile row R for tap dx is R + 1 + dx
     const unsigned lds0 = lds_addr(smem);
+    // (computed by late_setup(), behind the prologue's DMA issue: this arithmetic then runs under the loads'
+    // latency instead of in front of it — at one workgroup per CU nothing else covers either)
     unsigned fb[3][2];
-#pragma unroll
-    for (int dxi = 0; dxi < 3; ++dxi) {
-      const int rr = frow + DXR * dxi;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        fb[dxi][ks] = lds0 + (wm * WR + rr) * 128 + (((ks * 4 + fk) ^ swz_img(rr)) << 4);
-    }
     const unsigned zb[2] = {lds0 + ZOFF, lds0 + ZOFF - IMG};       // + ib*IMG + immediate lands in the zero region
     // ---- dx border masks: fragment f = FH*h + i of this wave row = tile rows wm*WR + 16*f + frow.  A
     // fragment's 16 pixels are lanes 0..15 (lanes l, l+16, l+32, l+48 hold the same pixel), so a mask is a
     // 16-bit pattern: 16 patterns packed in 8 SGPRs, widened to a wave mask where they are used (SALU)
     unsigned pm_m1[FH], pm_p1[FH];
-    {
+    auto late_setup = [&]() {
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        const int rr = frow + DXR * dxi;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          fb[dxi][ks] = lds0 + (wm * WR + rr) * 128 + (((ks * 4 + fk) ^ swz_img(rr)) << 4);
+      }
       // (POOL: a tile row is half a pixel column step: 16 rows = 8 columns)
       const int step16 = (POOL ? 8 : 16) % p.W;
       int w = (POOL ? (m0 + wm * WR + frow) >> 1 : m0 + wm * WR + frow) % p.W;
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
         w += step16;
         if (w >= p.W) w -= p.W;
       }
-    }
+    };
     auto wave_mask = [](unsigned packed, int f) -> unsigned long long {
       const unsigned p16 = (f & 1) ? packed >> 16 : packed & 0xFFFFu;
       const unsigned m32 = p16 | (p16 << 16);
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void igemm_nt_kernel(const IgemmPar
     issue_slot(J3{}, J0{}, 0, 0u);
     issue_B3(J1{}, J0{}, 0u);
     issue_B3(J0{}, J1{}, c2);
+    late_setup();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the zero-region stores
     __builtin_amdgcn_s_barrier();
